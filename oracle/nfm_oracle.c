@@ -1,0 +1,151 @@
+/* nfm_oracle.c -- CPU restatement of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is the parity checker for the HIP
+ * backend: it may be loaded by tests/, by __graft_entry__.smoke() and by
+ * bench.py's `cpu_baseline` leg, and by nothing else.  The product package
+ * (nitorch_fastmath_amd) never imports, links or calls it and has no CPU
+ * fallback of any kind.
+ *
+ * What it restates (file:line relative to /root/reference/nitorch_fastmath/):
+ *   _impl/sym.py:16-60     sym_to_full
+ *   _impl/sym.py:87-172    sym_matvec (+ add/sub forms named in sym.py:31-32)
+ *   _impl/sym.py:186-398   sym_solve: closed forms M<=4, full + LU for M>4
+ *   _impl/sym.py:401-452   sym_det (with quirk Q2 fixed: M from the compact dim)
+ *   _impl/sym.py:455-493   sym_invert = M solves against basis vectors
+ *   _impl/sym.py:496-670   sym_outer, sym_matmul (jhjn order)
+ *   _impl/batched.py:21-190 batchdet / batchinv / batchmatvec (CPU = torch LU
+ *                          fallbacks; TorchScript adjugate forms behind `closed`)
+ *   reduce.py:255-510      nansum / nanmax / nanmin / sum / max / min
+ *
+ * Pinning: checked against golden vectors produced by the real reference in
+ * the build container (tests/golden/make_golden.py -> tests/golden/ npz files);
+ * see tests/test_oracle_golden.py.  The closed forms (M <= 4) follow the
+ * reference's operation order exactly and are compiled with -ffp-contract=off.
+ *
+ * Layout: every operand is contiguous, batch-major ("AoS"): mat (n, K),
+ * vec (n, M), full matrices (n, N, N) row-major.  dtype: 0 = f32, 1 = f64.
+ */
+#include <stdint.h>
+#include <math.h>
+#include <stddef.h>
+
+#define NFM_MAXM 16
+
+#define T float
+#define SUF f32
+#define FABS fabsf
+#define ADDCMUL(self, a, b) fmaf((a), (b), (self))
+#include "nfm_oracle_body.inc"
+#undef T
+#undef SUF
+#undef FABS
+#undef ADDCMUL
+
+#define T double
+#define SUF f64
+#define FABS fabs
+#define ADDCMUL(self, a, b) fma((a), (b), (self))
+#include "nfm_oracle_body.inc"
+#undef T
+#undef SUF
+#undef FABS
+#undef ADDCMUL
+
+#define BAD_DTYPE (-2)
+#define BAD_SIZE (-3)
+#define CHECK_M(M) do { if ((M) < 1 || (M) > NFM_MAXM) return BAD_SIZE; } while (0)
+
+int nfm_oracle_sym_solve(int dtype, int M, int64_t n, int kind, const void *mat, const void *vec, void *out)
+{
+    CHECK_M(M);
+    if (dtype == 0) return nfm_oracle_sym_solve_f32(M, n, kind, mat, vec, out);
+    if (dtype == 1) return nfm_oracle_sym_solve_f64(M, n, kind, mat, vec, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_sym_matvec(int dtype, int M, int64_t n, int kind, int sign, const void *mat, const void *vec,
+                          const void *inp, void *out)
+{
+    CHECK_M(M);
+    if (dtype == 0) return nfm_oracle_sym_matvec_f32(M, n, kind, sign, mat, vec, inp, out);
+    if (dtype == 1) return nfm_oracle_sym_matvec_f64(M, n, kind, sign, mat, vec, inp, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_sym_invert(int dtype, int M, int64_t n, int diag_only, const void *mat, void *out)
+{
+    CHECK_M(M);
+    if (dtype == 0) return nfm_oracle_sym_invert_f32(M, n, diag_only, mat, out);
+    if (dtype == 1) return nfm_oracle_sym_invert_f64(M, n, diag_only, mat, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_sym_det(int dtype, int M, int64_t n, const void *mat, void *out)
+{
+    CHECK_M(M);
+    if (dtype == 0) return nfm_oracle_sym_det_f32(M, n, mat, out);
+    if (dtype == 1) return nfm_oracle_sym_det_f64(M, n, mat, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_sym_to_full(int dtype, int M, int64_t n, const void *mat, void *out)
+{
+    CHECK_M(M);
+    if (dtype == 0) return nfm_oracle_sym_to_full_f32(M, n, mat, out);
+    if (dtype == 1) return nfm_oracle_sym_to_full_f64(M, n, mat, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_sym_outer(int dtype, int M, int64_t n, const void *x, void *out)
+{
+    CHECK_M(M);
+    if (dtype == 0) return nfm_oracle_sym_outer_f32(M, n, x, out);
+    if (dtype == 1) return nfm_oracle_sym_outer_f64(M, n, x, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_sym_matmul(int dtype, int K, int D, int64_t n, int hess_diag, const void *jac, const void *hess,
+                          void *out)
+{
+    CHECK_M(K);
+    CHECK_M(D);
+    if (dtype == 0) return nfm_oracle_sym_matmul_f32(K, D, n, hess_diag, jac, hess, out);
+    if (dtype == 1) return nfm_oracle_sym_matmul_f64(K, D, n, hess_diag, jac, hess, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_batch_inv(int dtype, int N, int64_t n, int closed, const void *a, void *out)
+{
+    CHECK_M(N);
+    if (dtype == 0) return nfm_oracle_batch_inv_f32(N, n, closed, a, out);
+    if (dtype == 1) return nfm_oracle_batch_inv_f64(N, n, closed, a, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_batch_det(int dtype, int N, int64_t n, int closed, const void *a, void *out)
+{
+    CHECK_M(N);
+    if (dtype == 0) return nfm_oracle_batch_det_f32(N, n, closed, a, out);
+    if (dtype == 1) return nfm_oracle_batch_det_f64(N, n, closed, a, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_batch_matvec(int dtype, int rows, int cols, int64_t n, const void *a, const void *v, void *out)
+{
+    CHECK_M(rows);
+    CHECK_M(cols);
+    if (dtype == 0) return nfm_oracle_batch_matvec_f32(rows, cols, n, a, v, out);
+    if (dtype == 1) return nfm_oracle_batch_matvec_f64(rows, cols, n, a, v, out);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_reduce(int dtype, int op, int64_t outer, int64_t red, int64_t inner, const void *x, void *out,
+                      int out_f64)
+{
+    if (op < 0 || op > 5) return BAD_SIZE;
+    if (dtype == 0) return nfm_oracle_reduce_f32(op, outer, red, inner, x, out, out_f64);
+    if (dtype == 1) return nfm_oracle_reduce_f64(op, outer, red, inner, x, out, out_f64);
+    return BAD_DTYPE;
+}
+
+int nfm_oracle_version(void) { return 1; }
