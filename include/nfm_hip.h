@@ -1,0 +1,173 @@
+/* nfm_hip.h -- C ABI of libnfm_hip.so, the MI355X (gfx950) backend for the
+ * per-element small-matrix hot path of nitorch-fastmath.
+ *
+ * The reference has no FFI of its own for this path: its public functions are
+ * plain Python (`nitorch_fastmath/sym.py:28-37`, `batched.py:16-17`,
+ * `qr.py:1-11`, `reduce.py:38-41`) and the shipped `sym_*` implementation comes
+ * from the external `jitfields.sym` module (`sym.py:37`).  This header is the
+ * boundary a maintainer binds instead (ctypes stub in INTEGRATION.md): one
+ * entry point per reference function family, plain pointers / sizes / strides,
+ * no torch types.  Every entry point
+ *   - launches asynchronously on the `hipStream_t` passed as `stream`
+ *     (NULL = the default stream) on the CURRENT device, never synchronises,
+ *     never allocates or frees memory (graph-capture safe);
+ *   - returns 0 on success, a negative NFM_E* code for a rejected argument,
+ *     or a positive hipError_t if the launch itself failed;
+ *   - is reentrant and stateless.
+ *
+ * Batch model.  The facade flattens the broadcast batch shape to two levels,
+ * n_outer x n_inner (n_outer == 1 for ordinary contiguous tensors; two levels
+ * cover channel-first fields (B, C, *spatial) without a copy).  Strides are in
+ * ELEMENTS; 0 = broadcast.  An operand is read as
+ *     ptr[o * stride_outer + i * stride_inner + r * stride_row + c * stride_col]
+ * with (r, c) the matrix row/column for full matrices and r = 0, c = component
+ * for vectors and compact-symmetric storage.
+ *
+ * Compact symmetric layout (reference `sym.py:7-14`, `_impl/sym.py:21-27`):
+ * K = M(M+1)/2 components, the diagonal first, then the strict upper triangle
+ * row by row: [a00 a11 .. a(M-1)(M-1) | a01 a02 .. a0(M-1) a12 ..].
+ */
+#ifndef NFM_HIP_H
+#define NFM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFM_VERSION 1
+#define NFM_MAX_DIM 16 /* largest matrix order handled (3x3 .. 16x16 and below) */
+
+/* dtype codes */
+#define NFM_F32 0
+#define NFM_F64 1
+
+/* error codes (negative) */
+#define NFM_OK 0
+#define NFM_EINVAL (-1)   /* null pointer / negative size / bad flag */
+#define NFM_EDTYPE (-2)   /* unsupported dtype code */
+#define NFM_ESIZE (-3)    /* matrix order outside 1..NFM_MAX_DIM, or batch too large */
+#define NFM_EALIGN (-4)   /* pointer not aligned to the element size */
+#define NFM_EWORKSPACE (-5) /* workspace too small */
+
+/* `mat_kind` of the sym_* entry points: how the matrix operand's last dim of
+ * length NN is interpreted, reference `sym.py:16-24`. */
+#define NFM_MAT_SYM 0  /* NN = M(M+1)/2 compact symmetric */
+#define NFM_MAT_DIAG 1 /* NN = M       diagonal           */
+#define NFM_MAT_SCAL 2 /* NN = 1       scaled identity    */
+#define NFM_MAT_FULL 3 /* NN = M*M     full, row-major via stride_row/stride_col */
+
+typedef struct nfm_operand {
+    void *ptr;            /* device pointer */
+    int64_t stride_outer; /* elements */
+    int64_t stride_inner; /* elements */
+    int64_t stride_row;   /* elements; full matrices only */
+    int64_t stride_col;   /* elements; component stride for vectors / compact storage */
+} nfm_operand;
+
+/* ------------------------------------------------------------------ sym ---- */
+
+/* x = mat \ vec.  Replaces `sym_solve` / `sym_solve_` (`sym.py:33`; in-repo
+ * implementation `_impl/sym.py:327-398`).  M <= 4: the reference's closed forms,
+ * evaluated in its operation order (bit-identical to its CPU path); M > 4: LU with
+ * partial pivoting of the full matrix in registers / LDS, like the
+ * `torch.linalg.solve` branch (`_impl/sym.py:392-396`).  `eps` (NULL or M doubles on
+ * the HOST) is added to the diagonal first (documented intent of `_impl/sym.py:356-357`).
+ * `out` may alias `vec` (in-place variant). */
+int nfm_sym_solve(int dtype, int M, int mat_kind, int64_t n_outer, int64_t n_inner,
+                  const nfm_operand *mat, const nfm_operand *vec, const nfm_operand *out,
+                  const double *eps, void *stream);
+
+/* out = mat * vec            (mode  0)  `sym_matvec`        `_impl/sym.py:134-172`
+ * out = inp + mat * vec      (mode +1)  `sym_addmatvec(_)`  `sym.py:31`
+ * out = inp - mat * vec      (mode -1)  `sym_submatvec(_)`  `sym.py:32`
+ * `inp` is ignored for mode 0; `out` may alias `inp`. */
+int nfm_sym_matvec(int dtype, int M, int mat_kind, int mode, int64_t n_outer, int64_t n_inner,
+                   const nfm_operand *mat, const nfm_operand *vec, const nfm_operand *inp,
+                   const nfm_operand *out, void *stream);
+
+/* out = compact inverse of a compact symmetric matrix (diag_only: its M diagonal
+ * entries).  Replaces `sym_invert` / `sym_invert_` (`sym.py:34`, `_impl/sym.py:455-493`).
+ * One factorisation per matrix (the reference runs M full solves).  `out` may alias `mat`
+ * when diag_only == 0. */
+int nfm_sym_invert(int dtype, int M, int diag_only, int64_t n_outer, int64_t n_inner,
+                   const nfm_operand *mat, const nfm_operand *out, void *stream);
+
+/* determinant of compact symmetric matrices, `sym_det` `_impl/sym.py:401-452` (quirk Q2
+ * fixed: M comes from the compact dim).  out: one element per matrix (stride_col unused). */
+int nfm_sym_det(int dtype, int M, int64_t n_outer, int64_t n_inner, const nfm_operand *mat,
+                const nfm_operand *out, void *stream);
+
+/* compact -> full (M x M), `sym_to_full` `_impl/sym.py:16-60`. */
+int nfm_sym_to_full(int dtype, int M, int64_t n_outer, int64_t n_inner, const nfm_operand *mat,
+                    const nfm_operand *out, void *stream);
+
+/* compact x x^T of a vector, `sym_outer` `_impl/sym.py:496-528`. */
+int nfm_sym_outer(int dtype, int M, int64_t n_outer, int64_t n_inner, const nfm_operand *x,
+                  const nfm_operand *out, void *stream);
+
+/* compact J^T H J, `sym_matmul` `_impl/sym.py:637-670`; jac is (K x D) full, hess compact
+ * (hess_kind NFM_MAT_SYM) or diagonal (NFM_MAT_DIAG).  For K == D in {2, 3} the reference
+ * evaluates J H J^T (quirk Q16, `jhj2`/`jhj3` `_impl/sym.py:540-597`); so does this. */
+int nfm_sym_matmul(int dtype, int K, int D, int hess_kind, int64_t n_outer, int64_t n_inner,
+                   const nfm_operand *jac, const nfm_operand *hess, const nfm_operand *out,
+                   void *stream);
+
+/* -------------------------------------------------------------- batched ---- */
+
+#define NFM_FLAG_TS_PERTURB 1 /* add (max|A| - min|A|) * 1e-12 to det for N in {2,3}:
+                                 the TorchScript forms `inv2`/`inv3`, `_impl/batched.py:74-76,94-96` */
+
+/* out = a^-1 for general N x N matrices, `batchinv` `_impl/batched.py:101-130`.
+ * N <= 3: adjugate / det; N > 3: in-register Gauss-Jordan with partial pivoting
+ * (the reference falls back to LAPACK getrf/getri there).  out may alias a. */
+int nfm_batch_inv(int dtype, int N, int flags, int64_t n_outer, int64_t n_inner,
+                  const nfm_operand *a, const nfm_operand *out, void *stream);
+
+/* det(a), `batchdet` `_impl/batched.py:35-63`. */
+int nfm_batch_det(int dtype, int N, int64_t n_outer, int64_t n_inner, const nfm_operand *a,
+                  const nfm_operand *out, void *stream);
+
+/* out = a v for (rows x cols) matrices, `batchmatvec` `_impl/batched.py:154-190`. */
+int nfm_batch_matvec(int dtype, int rows, int cols, int64_t n_outer, int64_t n_inner,
+                     const nfm_operand *a, const nfm_operand *v, const nfm_operand *out,
+                     void *stream);
+
+/* ------------------------------------------------------------ reductions ---- */
+
+#define NFM_RED_NANSUM 0 /* `nansum` reduce.py:471-510 : NaN -> 0              */
+#define NFM_RED_NANMAX 1 /* `nanmax` reduce.py:255-316 : NaN -> -inf           */
+#define NFM_RED_NANMIN 2 /* `nanmin` reduce.py:319-380 : NaN -> +inf           */
+#define NFM_RED_SUM 3    /* `sum`    reduce.py:431-468 : NaN propagates        */
+#define NFM_RED_MAX 4    /* `max`    reduce.py:145-197                         */
+#define NFM_RED_MIN 5    /* `min`    reduce.py:200-252                         */
+#define NFM_RED_NANCOUNT 6 /* number of non-NaN elements (weights of `nanmean` reduce.py:591-594) */
+#define NFM_RED_NANSUMSQ 7 /* sum of squares of the non-NaN elements (`nanvar` reduce.py:679-680) */
+
+/* bytes of device workspace `nfm_reduce_all` needs (independent of n). */
+size_t nfm_reduce_workspace_bytes(void);
+
+/* Full reduction of n contiguous elements to ONE scalar.  Sums are accumulated in
+ * double whatever the input dtype; `out_dtype` is the dtype of *out (the `dtype=`
+ * argument of the reference functions).  n may exceed 2^32.  workspace: device
+ * memory of nfm_reduce_workspace_bytes() bytes, 16-byte aligned. */
+int nfm_reduce_all(int dtype, int op, int out_dtype, int64_t n, const void *x, void *workspace,
+                   size_t workspace_bytes, void *out, void *stream);
+
+/* Reduction over the middle axis of a contiguous (outer, red, inner) view; out is
+ * (outer, inner) of `out_dtype`; idx (may be NULL; max/min ops only) receives the
+ * int64 position along `red` of the selected element (first occurrence). */
+int nfm_reduce_dim(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner,
+                   const void *x, void *out, int64_t *idx, void *stream);
+
+/* ------------------------------------------------------------------- misc ---- */
+
+const char *nfm_strerror(int code);
+int nfm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFM_HIP_H */

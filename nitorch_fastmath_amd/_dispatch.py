@@ -1,0 +1,141 @@
+"""Host-side plumbing between torch tensors and the C ABI: dtype codes, stream,
+broadcast normalisation and the two-level batch collapse (no data movement unless
+the broadcast batch genuinely needs more than two stride levels)."""
+import torch
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise TypeError(f'nitorch_fastmath_amd supports float32 and float64 tensors, got {dtype}') from None
+
+
+def require_gpu(*tensors):
+    """The backend is HIP-only: refuse anything that is not on a ROCm/HIP device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                'nitorch_fastmath_amd runs on MI355X (HIP) tensors only; got a tensor on '
+                f'{t.device}. There is no CPU fallback: move the data with .cuda().')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f'all tensors must be on the same device ({dev} vs {t.device})')
+    return dev
+
+
+def no_grad_required(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            'nitorch_fastmath_amd kernels are forward-only (the reference documents that autograd '
+            'does not work through these functions either); call under torch.no_grad() or detach().')
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def common_dtype(dtype, *tensors):
+    if dtype is not None:
+        return dtype
+    out = None
+    for t in tensors:
+        if t is None:
+            continue
+        out = t.dtype if out is None else torch.promote_types(out, t.dtype)
+    return out
+
+
+def _collapse(shape, strides_list):
+    """Jointly merge adjacent batch dims that are mergeable for EVERY operand.
+    Returns (sizes, [strides per operand])."""
+    dims = [(s, [st[i] for st in strides_list]) for i, s in enumerate(shape) if s != 1]
+    if not dims:
+        return [], [[] for _ in strides_list]
+    merged = [dims[0]]
+    for s, sts in dims[1:]:
+        ps, psts = merged[-1]
+        if all(p == s * q for p, q in zip(psts, sts)):
+            merged[-1] = (ps * s, sts)
+        else:
+            merged.append((s, sts))
+    sizes = [m[0] for m in merged]
+    per_op = [[m[1][k] for m in merged] for k in range(len(strides_list))]
+    return sizes, per_op
+
+
+class Batch:
+    """Broadcast batch of several operands flattened to (n_outer, n_inner)."""
+
+    def __init__(self, batch_shape, tensors, ncomp, _copyback=None):
+        # tensors[k] has shape batch_shape + comp dims (ncomp[k] trailing dims), already
+        # expanded; the LAST tensor is the output.
+        nb = len(batch_shape)
+        self.shape = tuple(batch_shape)
+        self._copyback = _copyback
+        strides = [list(t.stride()[:nb]) for t in tensors]
+        sizes, per_op = _collapse(self.shape, strides)
+        if len(sizes) > 2:
+            # more than two stride levels: materialise (facade-allocated outputs are
+            # contiguous, so only exotic views pay this copy; a user-provided strided
+            # `out=` is written through a temporary and copied back by finish())
+            tensors = self._materialise(tensors)
+            strides = [list(t.stride()[:nb]) for t in tensors]
+            sizes, per_op = _collapse(self.shape, strides)
+            assert len(sizes) <= 1, sizes
+        self.tensors = tensors
+        numel = 1
+        for s in self.shape:
+            numel *= s
+        if numel == 0:
+            self.n_outer, self.n_inner = 0, 0
+            per_op = [[0, 0] for _ in tensors]
+        elif len(sizes) == 0:
+            self.n_outer, self.n_inner = 1, 1
+            per_op = [[0, 0] for _ in tensors]
+        elif len(sizes) == 1:
+            self.n_outer, self.n_inner = 1, sizes[0]
+            per_op = [[0, p[0]] for p in per_op]
+        else:
+            self.n_outer, self.n_inner = sizes
+        if self.n_outer > 65535:
+            # grid.y limit: fall back to one contiguous level
+            tensors = self._materialise(tensors)
+            self.__init__(batch_shape, tensors, ncomp, self._copyback)
+            return
+        self.operands = []
+        for t, (so, si), nc in zip(tensors, per_op, ncomp):
+            cs = t.stride()[nb:]
+            if nc == 2:
+                sr, sc = cs
+            elif nc == 1:
+                sr, sc = 0, cs[0]
+            else:
+                sr, sc = 0, 0
+            self.operands.append(_lib.Operand(t.data_ptr(), so, si, sr, sc))
+
+
+    def _materialise(self, tensors):
+        new = [t.contiguous() for t in tensors]
+        if new[-1] is not tensors[-1] and self._copyback is None:
+            self._copyback = (tensors[-1], new[-1])
+        return new
+
+    def finish(self):
+        """Copy a temporary output back into the user's strided `out=` tensor."""
+        if self._copyback is not None:
+            dst, src = self._copyback
+            dst.copy_(src)
+
+
+def expand_batch(batch_shape, t, ncomp):
+    """Expand `t` (batch dims + ncomp component dims) to the broadcast batch shape (a view)."""
+    comp = tuple(t.shape[t.dim() - ncomp:]) if ncomp else ()
+    return t.expand(tuple(batch_shape) + comp)

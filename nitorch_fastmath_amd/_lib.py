@@ -1,0 +1,81 @@
+"""ctypes binding of libnfm_hip.so (the C ABI declared in include/nfm_hip.h).
+
+The shared library is the product: there is NO fallback.  If it is missing, or a
+tensor does not live on a ROCm device, the call fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnfm_hip.so')
+
+F32, F64 = 0, 1
+MAT_SYM, MAT_DIAG, MAT_SCAL, MAT_FULL = 0, 1, 2, 3
+FLAG_TS_PERTURB = 1
+RED_NANSUM, RED_NANMAX, RED_NANMIN, RED_SUM, RED_MAX, RED_MIN, RED_NANCOUNT, RED_NANSUMSQ = range(8)
+MAX_DIM = 16
+
+
+class Operand(ctypes.Structure):
+    """struct nfm_operand (include/nfm_hip.h)"""
+    _fields_ = [('ptr', ctypes.c_void_p),
+                ('stride_outer', ctypes.c_int64),
+                ('stride_inner', ctypes.c_int64),
+                ('stride_row', ctypes.c_int64),
+                ('stride_col', ctypes.c_int64)]
+
+
+_i, _i64, _vp, _op = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(Operand)
+_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> argtypes; every symbol include/nfm_hip.h declares
+SIGNATURES = {
+    'nfm_sym_solve': [_i, _i, _i, _i64, _i64, _op, _op, _op, _dp, _vp],
+    'nfm_sym_matvec': [_i, _i, _i, _i, _i64, _i64, _op, _op, _op, _op, _vp],
+    'nfm_sym_invert': [_i, _i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_sym_det': [_i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_sym_to_full': [_i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_sym_outer': [_i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_sym_matmul': [_i, _i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
+    'nfm_batch_inv': [_i, _i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_batch_det': [_i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_batch_matvec': [_i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
+    'nfm_reduce_all': [_i, _i, _i, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    'nfm_reduce_dim': [_i, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP backend; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'nitorch_fastmath_amd: {LIB_PATH} is missing. Build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or '
+                '`make -C nitorch_fastmath_amd/csrc`. There is no CPU fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        L.nfm_strerror.argtypes = [ctypes.c_int]
+        L.nfm_strerror.restype = ctypes.c_char_p
+        L.nfm_version.argtypes = []
+        L.nfm_version.restype = ctypes.c_int
+        L.nfm_reduce_workspace_bytes.argtypes = []
+        L.nfm_reduce_workspace_bytes.restype = ctypes.c_size_t
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """C-ABI status -> Python exception (errors never cross the boundary as C++ throws)."""
+    if rc == 0:
+        return
+    msg = lib().nfm_strerror(rc).decode()
+    if rc < 0:
+        raise ValueError(f'nitorch_fastmath_amd: {msg} (code {rc})')
+    raise RuntimeError(f'nitorch_fastmath_amd: HIP error {rc}: {msg}')

@@ -1,0 +1,434 @@
+// nfm_smallmat.hpp -- per-lane small-matrix arithmetic (everything in registers,
+// every loop fully unrolled so that no array is ever indexed at run time).
+//
+// Closed forms for order <= 4 evaluate the reference's formulas in the reference's
+// operation order with contraction OFF, and use an explicit fma exactly where the
+// reference's ATen kernel is fused (`addcmul_`), so the results are bit-identical to
+// the reference's CPU TorchScript path.  File:line citations are relative to
+// /root/reference/nitorch_fastmath/.
+#pragma once
+#include "nfm_common.hpp"
+
+namespace nfm {
+
+template <typename T>
+__device__ __forceinline__ T fabs_(T x)
+{
+    return __builtin_elementwise_abs(x);
+}
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ----------------------------------------------------------------------------
+// compact symmetric, closed forms (M <= 4)
+// ----------------------------------------------------------------------------
+
+// _impl/sym.py:186-190  det = -(u0^2); det.addcmul_(d0, d1)
+template <typename T>
+__device__ __forceinline__ T sym_det2(const T *d, const T *u)
+{
+#pragma clang fp contract(off)
+    T det = -(u[0] * u[0]);
+    return fma_(d[0], d[1], det);
+}
+
+// _impl/sym.py:203-209
+template <typename T>
+__device__ __forceinline__ T sym_det3(const T *d, const T *u)
+{
+#pragma clang fp contract(off)
+    T pd = (d[0] * d[1]) * d[2];
+    T pu = (u[0] * u[1]) * u[2];
+    T t = (d[0] * (u[2] * u[2]) + d[2] * (u[0] * u[0])) + d[1] * (u[1] * u[1]);
+    return (pd + T(2) * pu) - t;
+}
+
+// _impl/sym.py:229-248
+template <typename T>
+__device__ __forceinline__ T sym_det4(const T *d, const T *u)
+{
+#pragma clang fp contract(off)
+    T s0 = u[0] * u[0], s1 = u[1] * u[1], s2 = u[2] * u[2];
+    T s3 = u[3] * u[3], s4 = u[4] * u[4], s5 = u[5] * u[5];
+    T q05 = u[0] * u[5], q14 = u[1] * u[4], q23 = u[2] * u[3];
+    T pd = ((d[0] * d[1]) * d[2]) * d[3];
+    T a = (q05 * q05 + q14 * q14) + q23 * q23;
+    T b = T(2) * ((((u[0] * u[1]) * u[4]) * u[5] + ((u[0] * u[2]) * u[3]) * u[5]) +
+                  ((u[1] * u[2]) * u[3]) * u[4]);
+    T c = T(2) * (((((d[0] * u[3]) * u[4]) * u[5] + ((d[1] * u[1]) * u[2]) * u[5]) +
+                   ((d[2] * u[0]) * u[2]) * u[4]) +
+                  ((d[3] * u[0]) * u[1]) * u[3]);
+    T e = ((((((d[0] * d[1]) * s5 + (d[0] * d[2]) * s4) + (d[0] * d[3]) * s3) + (d[1] * d[2]) * s2) +
+            (d[1] * d[3]) * s1) +
+           (d[2] * d[3]) * s0);
+    return (((pd + a) + (-b)) + c) - e;
+}
+
+// cofactors of a 4x4 compact matrix (the `inv??` terms and the diagonal brackets of
+// _impl/sym.py:251-322).  co[0..3] diagonal cofactors, co[4..9] = inv01 02 03 12 13 23.
+template <typename T>
+__device__ __forceinline__ void sym_cof4(const T *d, const T *u, T (&co)[10])
+{
+#pragma clang fp contract(off)
+    T s0 = u[0] * u[0], s1 = u[1] * u[1], s2 = u[2] * u[2];
+    T s3 = u[3] * u[3], s4 = u[4] * u[4], s5 = u[5] * u[5];
+    co[4] = ((((((-d[2]) * d[3]) * u[0] + (d[2] * u[2]) * u[4]) + (d[3] * u[1]) * u[3]) + u[0] * s5) -
+             (u[1] * u[4]) * u[5]) -
+            (u[2] * u[3]) * u[5];
+    co[5] = ((((((-d[1]) * d[3]) * u[1] + (d[1] * u[2]) * u[5]) + (d[3] * u[0]) * u[3]) + u[1] * s4) -
+             (u[0] * u[4]) * u[5]) -
+            (u[2] * u[3]) * u[4];
+    co[6] = ((((((-d[1]) * d[2]) * u[2] + (d[1] * u[1]) * u[5]) + (d[2] * u[0]) * u[4]) + u[2] * s3) -
+             (u[0] * u[3]) * u[5]) -
+            (u[1] * u[3]) * u[4];
+    co[7] = ((((((-d[0]) * d[3]) * u[3] + (d[0] * u[4]) * u[5]) + (d[3] * u[0]) * u[1]) + u[3] * s2) -
+             (u[0] * u[2]) * u[5]) -
+            (u[1] * u[2]) * u[4];
+    co[8] = ((((((-d[0]) * d[2]) * u[4] + (d[0] * u[3]) * u[5]) + (d[2] * u[0]) * u[2]) + u[4] * s1) -
+             (u[0] * u[1]) * u[5]) -
+            (u[1] * u[2]) * u[3];
+    co[9] = ((((((-d[0]) * d[1]) * u[5] + (d[0] * u[4]) * u[3]) + (d[1] * u[1]) * u[2]) + u[5] * s0) -
+             (u[0] * u[1]) * u[4]) -
+            (u[0] * u[2]) * u[3];
+    co[0] = ((((d[1] * d[2]) * d[3] - d[1] * s5) - d[2] * s4) - d[3] * s3) + ((T(2) * u[3]) * u[4]) * u[5];
+    co[1] = ((((d[0] * d[2]) * d[3] - d[0] * s5) - d[2] * s2) - d[3] * s1) + ((T(2) * u[1]) * u[2]) * u[5];
+    co[2] = ((((d[0] * d[1]) * d[3] - d[0] * s4) - d[1] * s2) - d[3] * s0) + ((T(2) * u[0]) * u[2]) * u[4];
+    co[3] = ((((d[0] * d[1]) * d[2] - d[0] * s3) - d[1] * s1) - d[2] * s0) + ((T(2) * u[0]) * u[1]) * u[3];
+}
+
+// cofactors of a 3x3 compact matrix, _impl/sym.py:216-224; co[0..2] diag, co[3..5] = 01 02 12
+template <typename T>
+__device__ __forceinline__ void sym_cof3(const T *d, const T *u, T (&co)[6])
+{
+#pragma clang fp contract(off)
+    co[0] = d[1] * d[2] - u[2] * u[2];
+    co[1] = d[0] * d[2] - u[1] * u[1];
+    co[2] = d[0] * d[1] - u[0] * u[0];
+    co[3] = u[1] * u[2] - d[2] * u[0];
+    co[4] = u[0] * u[2] - d[1] * u[1];
+    co[5] = u[0] * u[1] - d[0] * u[2];
+}
+
+// x = A^-1 v, compact A of order M <= 4, _impl/sym.py:193-200, 212-226, 251-324, 384-391
+template <typename T, int M>
+__device__ __forceinline__ void sym_solve_closed(const T (&m)[sym_k(M)], const T (&v)[M], T (&r)[M])
+{
+#pragma clang fp contract(off)
+    static_assert(M >= 1 && M <= 4, "closed forms exist for M <= 4");
+    if constexpr (M == 1) {
+        r[0] = v[0] / m[0];
+    } else if constexpr (M == 2) {
+        T det = sym_det2(&m[0], &m[2]);
+        r[0] = (m[1] * v[0] - m[2] * v[1]) / det;
+        r[1] = (m[0] * v[1] - m[2] * v[0]) / det;
+    } else if constexpr (M == 3) {
+        T det = sym_det3(&m[0], &m[3]);
+        T co[6];
+        sym_cof3(&m[0], &m[3], co);
+        r[0] = ((co[0] * v[0] + co[3] * v[1]) + co[4] * v[2]) / det;
+        r[1] = ((co[3] * v[0] + co[1] * v[1]) + co[5] * v[2]) / det;
+        r[2] = ((co[4] * v[0] + co[5] * v[1]) + co[2] * v[2]) / det;
+    } else {
+        T det = sym_det4(&m[0], &m[4]);
+        T co[10];
+        sym_cof4(&m[0], &m[4], co);
+        // res[i] = cof_ii * v[i]; res[i] += inv.. * v[..] in the reference's order
+        r[0] = (((co[0] * v[0] + co[4] * v[1]) + co[5] * v[2]) + co[6] * v[3]) / det;
+        r[1] = (((co[1] * v[1] + co[4] * v[0]) + co[7] * v[2]) + co[8] * v[3]) / det;
+        r[2] = (((co[2] * v[2] + co[5] * v[0]) + co[7] * v[1]) + co[9] * v[3]) / det;
+        r[3] = (((co[3] * v[3] + co[6] * v[0]) + co[8] * v[1]) + co[9] * v[2]) / det;
+    }
+}
+
+// compact inverse, order M <= 4: what `sym_invert` (_impl/sym.py:455-493) obtains by
+// solving against each basis vector = cofactor / det, in compact order.
+template <typename T, int M>
+__device__ __forceinline__ void sym_invert_closed(const T (&m)[sym_k(M)], T (&r)[sym_k(M)])
+{
+#pragma clang fp contract(off)
+    if constexpr (M == 1) {
+        r[0] = T(1) / m[0];
+    } else if constexpr (M == 2) {
+        T det = sym_det2(&m[0], &m[2]);
+        r[0] = m[1] / det;
+        r[1] = m[0] / det;
+        r[2] = (-m[2]) / det;
+    } else if constexpr (M == 3) {
+        T det = sym_det3(&m[0], &m[3]);
+        T co[6];
+        sym_cof3(&m[0], &m[3], co);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = co[i] / det;
+    } else {
+        T det = sym_det4(&m[0], &m[4]);
+        T co[10];
+        sym_cof4(&m[0], &m[4], co);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) r[i] = co[i] / det;
+    }
+}
+
+// y = A v, compact A: _impl/sym.py:87-131.  mm = diag * v, then one fused
+// `addcmul_` per off-diagonal entry, in the reference's order for each M.
+template <typename T, int M>
+__device__ __forceinline__ void sym_matvec_compact(const T (&m)[sym_k(M)], const T (&v)[M], T (&r)[M])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < M; ++i) r[i] = m[i] * v[i];
+    if constexpr (M >= 2 && M <= 4) {
+        // _sym_matvec2/3/4: row by row, each row's chain left to right
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j != i) r[i] = fma_(m[sym_idx(M, i, j)], v[j], r[i]);
+    } else if constexpr (M > 4) {
+        // _sym_matvecn: walk the upper triangle once, updating rows i and j
+        int c = M;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = i + 1; j < M; ++j) {
+                r[i] = fma_(m[c], v[j], r[i]);
+                r[j] = fma_(m[c], v[i], r[j]);
+                ++c;
+            }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// general N x N in registers
+// ----------------------------------------------------------------------------
+
+template <typename T, int M>
+__device__ __forceinline__ void sym_expand(const T (&m)[sym_k(M)], T (&a)[M][M])
+{
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) a[i][j] = m[sym_idx(M, i, j)];
+}
+
+// NB: registers cannot be indexed dynamically, so a run-time row swap k <-> p is
+// done with selects: every candidate row i > k exchanges with row k under (p == i).
+
+// Gaussian elimination with partial pivoting + back substitution on [A | B],
+// NR right-hand sides; B is overwritten by A^-1 B.  Mirrors LAPACK getrf/getrs
+// (what torch.linalg.solve runs on the reference's M > 4 branch,
+// _impl/sym.py:392-396): pivot = first largest |a_ik|, multipliers formed with
+// the reciprocal pivot, back substitution divides by the diagonal.
+template <typename T, int N, int NR>
+__device__ __forceinline__ void ge_solve(T (&a)[N][N], T (&b)[N][NR])
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if constexpr (N > 1) {
+            int p = k;
+            T best = fabs_(a[k][k]);
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const T x = fabs_(a[i][k]);
+                const bool g = x > best;
+                best = g ? x : best;
+                p = g ? i : p;
+            }
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const bool s = (p == i);
+#pragma unroll
+                for (int j = k; j < N; ++j) {
+                    const T t = a[k][j];
+                    a[k][j] = s ? a[i][j] : t;
+                    a[i][j] = s ? t : a[i][j];
+                }
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const T t = b[k][r];
+                    b[k][r] = s ? b[i][r] : t;
+                    b[i][r] = s ? t : b[i][r];
+                }
+            }
+        }
+        const T rp = T(1) / a[k][k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const T l = a[i][k] * rp;
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) a[i][j] -= l * a[k][j];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) b[i][r] -= l * b[k][r];
+        }
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            T s = b[i][r];
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) s -= a[i][j] * b[j][r];
+            b[i][r] = s / a[i][i];
+        }
+    }
+}
+
+// In-place Gauss-Jordan inverse with partial pivoting (N^2 registers, no second
+// matrix): row swaps during elimination, the matching column swaps undone at the
+// end.  Singular input -> inf/NaN, like the reference (no error).
+template <typename T, int N>
+__device__ __forceinline__ void gj_inverse(T (&a)[N][N])
+{
+    int piv[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int p = k;
+        if constexpr (N > 1) {
+            T best = fabs_(a[k][k]);
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const T x = fabs_(a[i][k]);
+                const bool g = x > best;
+                best = g ? x : best;
+                p = g ? i : p;
+            }
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const bool s = (p == i);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const T t = a[k][j];
+                    a[k][j] = s ? a[i][j] : t;
+                    a[i][j] = s ? t : a[i][j];
+                }
+            }
+        }
+        piv[k] = p;
+        const T rp = T(1) / a[k][k];
+        a[k][k] = T(1);
+#pragma unroll
+        for (int j = 0; j < N; ++j) a[k][j] *= rp;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i != k) {
+                const T f = a[i][k];
+                a[i][k] = T(0);
+#pragma unroll
+                for (int j = 0; j < N; ++j) a[i][j] -= f * a[k][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = N - 2; k >= 0; --k) {
+#pragma unroll
+        for (int c = k + 1; c < N; ++c) {
+            const bool s = (piv[k] == c);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const T t = a[i][k];
+                a[i][k] = s ? a[i][c] : t;
+                a[i][c] = s ? t : a[i][c];
+            }
+        }
+    }
+}
+
+// determinant by LU with partial pivoting (torch.det on the reference's fallbacks,
+// _impl/batched.py:53-54, _impl/sym.py:447-450)
+template <typename T, int N>
+__device__ __forceinline__ T lu_det(T (&a)[N][N])
+{
+    T det = T(1);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if constexpr (N > 1) {
+            int p = k;
+            T best = fabs_(a[k][k]);
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const T x = fabs_(a[i][k]);
+                const bool g = x > best;
+                best = g ? x : best;
+                p = g ? i : p;
+            }
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const bool s = (p == i);
+#pragma unroll
+                for (int j = k; j < N; ++j) {
+                    const T t = a[k][j];
+                    a[k][j] = s ? a[i][j] : t;
+                    a[i][j] = s ? t : a[i][j];
+                }
+            }
+            det = (p != k) ? -det : det;
+        }
+        const T pivot = a[k][k];
+        const T rp = T(1) / pivot;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const T l = a[i][k] * rp;
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) a[i][j] -= l * a[k][j];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) det *= a[k][k];
+    return det;
+}
+
+// ----------------------------------------------------------------------------
+// general small matrices, closed forms of _impl/batched.py (N <= 3)
+// ----------------------------------------------------------------------------
+template <typename T, int N>
+__device__ __forceinline__ T det_closed(const T (&A)[N * N])
+{
+#pragma clang fp contract(off)
+    if constexpr (N == 1) {
+        return A[0];
+    } else if constexpr (N == 2) { // det2 :21-24
+        return A[0] * A[3] - A[1] * A[2];
+    } else { // det3 :27-32
+        return (A[0] * (A[4] * A[8] - A[5] * A[7]) + A[1] * (A[5] * A[6] - A[3] * A[8])) +
+               A[2] * (A[3] * A[7] - A[4] * A[6]);
+    }
+}
+
+// inv2 / inv3, _impl/batched.py:66-98; `perturb` adds (max|A| - min|A|) * 1e-12 to det
+template <typename T, int N>
+__device__ __forceinline__ void inv_closed(const T (&A)[N * N], T (&F)[N * N], bool perturb)
+{
+#pragma clang fp contract(off)
+    if constexpr (N == 1) {
+        F[0] = T(1) / A[0]; // a.reciprocal() :128
+    } else {
+        T dt = det_closed<T, N>(A);
+        if (perturb) {
+            T amax = fabs_(A[0]), amin = fabs_(A[0]);
+#pragma unroll
+            for (int i = 1; i < N * N; ++i) {
+                const T x = fabs_(A[i]);
+                amax = x > amax ? x : amax;
+                amin = x < amin ? x : amin;
+            }
+            dt = dt + (amax - amin) * T(1E-12);
+        }
+        if constexpr (N == 2) {
+            F[0] = A[3] / dt;
+            F[1] = (-A[1]) / dt;
+            F[2] = (-A[2]) / dt;
+            F[3] = A[0] / dt;
+        } else {
+            F[0] = (A[4] * A[8] - A[5] * A[7]) / dt;
+            F[1] = (A[2] * A[7] - A[1] * A[8]) / dt;
+            F[2] = (A[1] * A[5] - A[2] * A[4]) / dt;
+            F[3] = (A[5] * A[6] - A[3] * A[8]) / dt;
+            F[4] = (A[0] * A[8] - A[2] * A[6]) / dt;
+            F[5] = (A[3] * A[2] - A[5] * A[0]) / dt;
+            F[6] = (A[7] * A[3] - A[6] * A[4]) / dt;
+            F[7] = (A[6] * A[1] - A[7] * A[0]) / dt;
+            F[8] = (A[0] * A[4] - A[1] * A[3]) / dt;
+        }
+    }
+}
+
+} // namespace nfm

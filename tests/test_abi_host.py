@@ -1,0 +1,150 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol declared in
+include/nfm_hip.h, argument validation answers without touching a GPU, and the
+host-side batch normalisation does what the kernels assume."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT
+
+
+@pytest.fixture(scope='module')
+def L():
+    import __graft_entry__ as G
+    if not os.path.exists(os.path.join(ROOT, 'nitorch_fastmath_amd', 'libnfm_hip.so')):
+        G.build()
+    from nitorch_fastmath_amd import _lib
+    return _lib.lib()
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'nfm_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(nfm_[a-z_0-9]+)\s*\(', txt)))
+
+
+def test_exports_every_declared_symbol(L):
+    syms = declared_symbols()
+    assert len(syms) >= 15, syms
+    for s in syms:
+        assert hasattr(L, s), f'{s} declared in include/nfm_hip.h but not exported'
+
+
+def test_signature_table_matches_header():
+    from nitorch_fastmath_amd import _lib
+    declared = set(declared_symbols())
+    bound = set(_lib.SIGNATURES) | {'nfm_strerror', 'nfm_version', 'nfm_reduce_workspace_bytes'}
+    assert declared == bound, declared ^ bound
+
+
+def test_version_and_strerror(L):
+    assert L.nfm_version() == 1
+    assert b'dtype' in L.nfm_strerror(-2)
+    assert L.nfm_reduce_workspace_bytes() >= 2048 * 8
+
+
+def test_argument_validation_without_gpu(L):
+    from nitorch_fastmath_amd._lib import Operand
+    op = Operand(None, 0, 0, 0, 1)
+    r = ctypes.byref(op)
+    # bad dtype / bad order / negative batch are rejected before any HIP call
+    assert L.nfm_sym_solve(7, 4, 0, 1, 1, r, r, r, None, None) == -2
+    assert L.nfm_sym_solve(0, 17, 0, 1, 1, r, r, r, None, None) == -3
+    assert L.nfm_sym_solve(0, 4, 0, 1, -1, r, r, r, None, None) == -1
+    assert L.nfm_sym_solve(0, 4, 9, 1, 1, r, r, r, None, None) == -1
+    assert L.nfm_sym_solve(0, 4, 0, 1, 5, r, r, r, None, None) == -1   # null pointers, n > 0
+    assert L.nfm_batch_inv(0, 0, 0, 1, 1, r, r, None) == -3
+    assert L.nfm_reduce_all(0, 99, 0, 0, None, 8, 1 << 20, 8, None) == -1
+    assert L.nfm_reduce_all(0, 0, 0, 0, None, 8, 16, 8, None) == -5     # workspace too small
+    # empty batches succeed without a launch
+    assert L.nfm_sym_solve(0, 4, 0, 1, 0, r, r, r, None, None) == 0
+    assert L.nfm_sym_invert(1, 3, 0, 0, 0, r, r, None) == 0
+    bad = Operand(6, 0, 0, 0, 1)   # misaligned for float
+    assert L.nfm_sym_det(0, 3, 1, 1, ctypes.byref(bad), ctypes.byref(bad), None) == -4
+
+
+def test_facade_refuses_cpu_tensors_and_bad_dtypes():
+    import nitorch_fastmath_amd as N
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        N.sym_solve(torch.ones(5, 10), torch.ones(5, 4))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        N.batchinv(torch.eye(3)[None])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        N.reduce.nansum(torch.ones(4))
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: no product source may reference it
+    pkg = os.path.join(ROOT, 'nitorch_fastmath_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.lower(), f'{f} mentions the oracle'
+
+
+def test_batch_collapse():
+    from nitorch_fastmath_amd._dispatch import Batch, expand_batch
+    # contiguous (B, X, K) collapses to one level
+    mat = torch.zeros(6, 7, 10)
+    vec = torch.zeros(6, 7, 4)
+    out = torch.zeros(6, 7, 4)
+    b = Batch((6, 7), [mat, vec, out], [1, 1, 1])
+    assert (b.n_outer, b.n_inner) == (1, 42)
+    assert [o.stride_inner for o in b.operands] == [10, 4, 4]
+    assert [o.stride_col for o in b.operands] == [1, 1, 1]
+    # channel-first field (B, C, X, Y) viewed as (B, X, Y, C): two levels, no copy
+    f = torch.zeros(3, 10, 5, 8)
+    m = f.movedim(1, -1)
+    v = torch.zeros(3, 4, 5, 8).movedim(1, -1)
+    o = torch.zeros(3, 5, 8, 4)
+    b = Batch((3, 5, 8), [m, v, o], [1, 1, 1])
+    assert (b.n_outer, b.n_inner) == (3, 40)
+    assert b.operands[0].stride_outer == 400 and b.operands[0].stride_inner == 1
+    assert b.operands[0].stride_col == 40 and b.operands[2].stride_inner == 4
+    assert b.tensors[0].data_ptr() == f.data_ptr()
+    # broadcast matrix: stride 0 at both levels
+    m1 = expand_batch((6, 7), torch.zeros(10), 1)
+    b = Batch((6, 7), [m1, vec, out], [1, 1, 1])
+    assert (b.n_outer, b.n_inner) == (1, 42) and b.operands[0].stride_inner == 0
+    # partially broadcast: (1, 7, K) against (6, 7, M) -> two levels, outer stride 0
+    m2 = expand_batch((6, 7), torch.zeros(1, 7, 10), 1)
+    b = Batch((6, 7), [m2, vec, out], [1, 1, 1])
+    assert (b.n_outer, b.n_inner) == (6, 7)
+    assert b.operands[0].stride_outer == 0 and b.operands[0].stride_inner == 10
+    # three genuine levels -> materialised
+    t = torch.zeros(4, 2, 6, 2, 5, 10)[:, 0, :, 0]      # (4, 6, 5, 10), strides (1200, 100, 10, 1)
+    t = t[:, ::2, ::2]                                    # (4, 3, 3, 10)
+    b = Batch((4, 3, 3), [t, torch.zeros(4, 3, 3, 10)], [1, 1])
+    assert (b.n_outer, b.n_inner) == (1, 36)
+    # empty batch
+    b = Batch((0, 5), [torch.zeros(0, 5, 10), torch.zeros(0, 5, 4)], [1, 1])
+    assert b.n_outer == 0 and b.n_inner == 0
+    # full matrices carry row/col strides
+    a = torch.zeros(9, 3, 3).transpose(-1, -2)
+    b = Batch((9,), [a, torch.zeros(9, 3, 3)], [2, 2])
+    assert (b.operands[0].stride_row, b.operands[0].stride_col) == (1, 3)
+
+
+def test_mat_kind_and_utils():
+    from nitorch_fastmath_amd import sym, utils, _lib
+    assert sym._mat_kind(10, 4) == _lib.MAT_SYM
+    assert sym._mat_kind(4, 4) == _lib.MAT_DIAG
+    assert sym._mat_kind(1, 4) == _lib.MAT_SCAL
+    assert sym._mat_kind(16, 4) == _lib.MAT_FULL
+    assert sym._mat_kind(1, 1) == _lib.MAT_SYM
+    with pytest.raises(ValueError):
+        sym._mat_kind(7, 4)
+    assert sym._nb_prm(21) == 6
+    with pytest.raises(ValueError):
+        sym._nb_prm(7)
+    ind = torch.tensor([0, 5, 23])
+    sub = utils.ind2sub(ind, [2, 3, 4])
+    assert sub.tolist() == np.array(np.unravel_index([0, 5, 23], (2, 3, 4))).tolist()
+    assert utils.sub2ind(list(sub), [2, 3, 4]).tolist() == [0, 5, 23]
+    assert utils.ensure_list(3, 2) == [3, 3] and utils.ensure_list((1, 2)) == [1, 2]
+    assert utils.eps(torch.float32) == 2 ** -23 and utils.eps('float64') == 2 ** -52
+    x = torch.zeros(3, 6)
+    assert sym.sym_diag(x).shape == (3, 3) and sym.sym_diag(x).data_ptr() == x.data_ptr()

@@ -1,0 +1,179 @@
+"""GPU parity tests for the NaN-omitting reductions."""
+import numpy as np
+import pytest
+import torch
+from conftest import TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def R():
+    import nitorch_fastmath_amd as N_
+    return N_.reduce
+
+
+def t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def same(r, e):
+    r, e = float(r), float(e)
+    return (np.isnan(r) and np.isnan(e)) or r == e
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('size', [1, 63, 64, 65, 4097, 20011])
+@pytest.mark.parametrize('nn', ['nan0', 'nan1', 'nanall'])
+def test_golden_full(dev, golden_reduce, dn, size, nn):
+    g, k = golden_reduce, f'{dn}_{size}_{nn}_'
+    x = g[k + 'x']
+    xd = t(x, dev)
+    fin = x[np.isfinite(x)]
+    scale = max(float(np.abs(fin).sum()), 1e-30)
+    for op in ('nansum', 'sum', 'mean'):
+        r, e = getattr(R(), op)(xd), g[k + op]
+        assert r.dim() == 0 and r.dtype == xd.dtype
+        s = scale / (size if op == 'mean' else 1)
+        assert same(r, e) or abs(float(r) - float(e)) <= TOL[dn] * s, (op, float(r), float(e))
+    r = R().nansum(xd, dtype=torch.float64)
+    assert r.dtype == torch.float64
+    assert same(r, g[k + 'nansum64']) or abs(float(r) - float(g[k + 'nansum64'])) <= 1e-12 * scale
+    for op in ('nanmax', 'nanmin', 'max', 'min'):
+        assert same(getattr(R(), op)(xd), g[k + op]), op
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_golden_dims(dev, golden_reduce, dn):
+    g = golden_reduce
+    x = g[dn + '_nd_x']
+    xd = t(x, dev)
+    for dim, name in ((0, 'd0'), (1, 'd1'), (2, 'd2'), (-1, 'dm1'), ((0, 2), 'd02'), ((1, 2), 'd12')):
+        for fn, key in ((R().nansum, 'nansum'), (R().sum, 'sum'), (R().mean, 'mean')):
+            r = fn(xd, dim=dim).cpu().numpy()
+            e = g[f'{dn}_nd_{key}_{name}']
+            assert r.shape == e.shape
+            assert np.array_equal(np.isnan(r), np.isnan(e))
+            assert np.abs(np.nan_to_num(r) - np.nan_to_num(e)).max() <= TOL[dn] * 40
+        rk = R().nansum(xd, dim=dim, keepdim=True)
+        assert tuple(rk.shape) == g[f'{dn}_nd_nansum_keep_{name}'].shape
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('n', [0, 3, 1000, (1 << 20) + 77, 5_000_011])
+def test_vs_oracle_full(dev, oracle, dn, n):
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(n + 1)
+    x = rng.standard_normal(n).astype(dtype)
+    x[rng.random(n) < 0.01] = np.nan
+    for off in (0, 1, 3):      # unaligned base pointers take the scalar head path
+        xs = x[off:]
+        xd = t(x, dev)[off:]
+        if xs.size == 0:
+            assert float(R().nansum(xd)) == 0.0
+            continue
+        scale = max(float(np.nansum(np.abs(xs))), 1e-30)
+        r = float(R().nansum(xd, dtype=torch.float64))
+        assert abs(r - float(oracle.reduce('nansum', xs, out_f64=True))) <= 1e-12 * scale
+        assert abs(float(R().nansum(xd)) - float(oracle.reduce('nansum', xs, out_f64=True))) <= TOL[dn] * scale
+        assert float(R().nanmax(xd)) == float(oracle.reduce('nanmax', xs))
+        assert float(R().nanmin(xd)) == float(oracle.reduce('nanmin', xs))
+        assert np.isnan(float(R().max(xd))) == bool(np.isnan(xs).any())
+        # deterministic
+        assert float(R().nansum(xd, dtype=torch.float64)) == r
+
+
+def test_special_values(dev):
+    inf = float('inf')
+    x = torch.tensor([1.0, float('nan'), -inf, 5.0, inf, float('nan')], device=dev)
+    assert float(R().nanmax(x)) == inf and float(R().nanmin(x)) == -inf
+    assert np.isnan(float(R().nansum(x)))                 # inf + -inf
+    assert float(R().nansum(x[:4])) == -inf
+    y = torch.full((1000,), float('nan'), device=dev)
+    assert float(R().nansum(y)) == 0.0
+    assert float(R().nanmax(y)) == -inf and float(R().nanmin(y)) == inf
+    assert np.isnan(float(R().nanmean(y)))
+    assert R().nansum(y, keepdim=True).shape == (1,)
+    out = torch.empty((), device=dev)
+    assert R().nansum(x[:1], out=out).data_ptr() == out.data_ptr() and float(out) == 1.0
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_dim_semantics_vs_numpy(dev, dn):
+    """functions that raise upstream (quirks Q10-Q13) follow their documented
+    semantics; numpy's nan-functions are the independent check."""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((5, 70, 6, 33)).astype(dtype)
+    x[rng.random(x.shape) < 0.05] = np.nan
+    x[2, :, 3, 7] = np.nan                        # an all-NaN reduced slice for dim=1
+    xd = t(x, dev)
+    tol = 2e-6 if dn == 'f32' else 1e-12
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for dim in (0, 1, 3, -1, (1, 2), (0, 3), (2, 1)):
+            ax = dim
+            for name, npf in (('nanmax', np.nanmax), ('nanmin', np.nanmin)):
+                r = getattr(R(), name)(xd, dim=dim).cpu().numpy()
+                e = npf(x, axis=ax)
+                fill = -np.inf if name == 'nanmax' else np.inf
+                e = np.where(np.isnan(e), fill, e)     # all-NaN -> -inf / +inf like the reference
+                assert r.shape == e.shape and np.array_equal(r, e), (name, dim)
+            r = R().nanmean(xd, dim=dim).cpu().numpy()
+            e = np.nanmean(x.astype(np.float64), axis=ax)
+            assert np.array_equal(np.isnan(r), np.isnan(e))
+            assert np.nanmax(np.abs(r - e)) <= tol * 5
+            for unb in (True, False):
+                r = R().nanvar(xd, dim=dim, unbiased=unb).cpu().numpy()
+                e = np.nanvar(x.astype(np.float64), axis=ax, ddof=int(unb))
+                ok = np.isfinite(e)
+                assert np.abs(r[ok] - e[ok]).max() <= tol * 20
+                r = R().nanstd(xd, dim=dim, unbiased=unb).cpu().numpy()
+                assert np.abs(r[ok] - np.sqrt(e[ok])).max() <= tol * 20
+            # NaN-propagating forms
+            r = R().max(xd, dim=dim).cpu().numpy()
+            e = np.max(x, axis=ax)
+            assert np.array_equal(np.isnan(r), np.isnan(e)) and np.array_equal(np.nan_to_num(r), np.nan_to_num(e))
+            r = R().var(xd, dim=dim).cpu().numpy()
+            e = np.var(x.astype(np.float64), axis=ax, ddof=1)
+            assert np.array_equal(np.isnan(r), np.isnan(e))
+    # indices: (..., len(dim)) in C order over the reduced dims; scalar dim drops the axis
+    v, i = R().nanmax(xd, dim=1, return_indices=True)
+    xx = np.where(np.isnan(x), -np.inf, x)
+    assert np.array_equal(i.cpu().numpy(), xx.argmax(axis=1))
+    v, i = R().nanmin(xd, dim=(1, 2), return_indices=True)
+    xx = np.where(np.isnan(x), np.inf, x)
+    flat = xx.transpose(0, 3, 1, 2).reshape(5, 33, -1).argmin(-1)
+    e = np.stack(np.unravel_index(flat, (70, 6)), -1)
+    assert i.shape == (5, 33, 2) and np.array_equal(i.cpu().numpy(), e)
+    v, i = R().max(xd, dim=[3], keepdim=True, return_indices=True)
+    assert v.shape == (5, 70, 6, 1) and i.shape == (5, 70, 6, 1, 1)
+    # first NaN position for the propagating max
+    e = np.where(np.isnan(x).any(3), np.isnan(x).argmax(3), np.nan_to_num(x, nan=-np.inf).argmax(3))
+    assert np.array_equal(i.cpu().numpy()[..., 0, 0], e)
+    # non-contiguous input
+    r = R().nansum(xd.transpose(0, 2), dim=1).cpu().numpy()
+    e = np.nansum(x.transpose(2, 1, 0, 3).astype(np.float64), axis=1)
+    assert np.abs(r - e).max() <= tol * 100
+
+
+def test_large_full_reduction_properties(dev):
+    """C4-shaped check at 2^28 elements (1 GiB fp32): split-additivity, permutation
+    invariance to rounding, exact max/min, NaN count."""
+    n = 1 << 28
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn(n, device=dev, generator=g)
+    mask = torch.rand(n, device=dev, generator=g) < 0.01
+    x[mask] = float('nan')
+    s = float(R().nansum(x, dtype=torch.float64))
+    h = n // 2 + 12345
+    s2 = float(R().nansum(x[:h], dtype=torch.float64)) + float(R().nansum(x[h:], dtype=torch.float64))
+    tot = float(torch.nan_to_num(x).abs().sum(dtype=torch.float64))
+    assert abs(s - s2) <= 1e-12 * tot
+    ref = float(torch.nan_to_num(x).sum(dtype=torch.float64))
+    assert abs(s - ref) <= 1e-12 * tot
+    assert abs(float(R().nansum(x)) - ref) <= 1e-6 * tot
+    assert float(R().nanmax(x)) == float(torch.nan_to_num(x, nan=-float('inf')).max())
+    assert float(R().nanmin(x)) == float(torch.nan_to_num(x, nan=float('inf')).min())
+    cnt = float(R().nanmean(x, dtype=torch.float64))
+    assert abs(cnt - ref / float((~mask).sum())) <= 1e-12

@@ -1,0 +1,229 @@
+"""GPU parity tests (through the C ABI) for the compact-symmetric family.
+Oracle = CPU restatement pinned to the reference's golden vectors; tolerances are
+BASELINE.json's: 1e-6 rel fp32 / 1e-12 rel fp64 (max-norm), bit-exact where the
+closed forms apply (M <= 4)."""
+import numpy as np
+import pytest
+import torch
+from conftest import TOL, relerr
+
+pytestmark = pytest.mark.gpu
+MS = (1, 2, 3, 4, 5, 6, 7, 8, 12, 16)
+DT = {'f32': torch.float32, 'f64': torch.float64}
+
+
+def N():
+    import nitorch_fastmath_amd as N_
+    return N_
+
+
+def t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def spd_np(n, M, dtype, seed):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, M, M))
+    A = G @ G.transpose(0, 2, 1) / M + np.eye(M)
+    iu = [(i, j) for i in range(M) for j in range(i + 1, M)]
+    c = np.concatenate([np.stack([A[:, i, i] for i in range(M)], -1)] +
+                       ([np.stack([A[:, i, j] for i, j in iu], -1)] if iu else []), -1)
+    return c.astype(dtype), rng.standard_normal((n, M)).astype(dtype)
+
+
+def check(got, ref, dn, exact):
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    if exact:
+        assert np.array_equal(got, ref), relerr(got, ref)
+    else:
+        assert relerr(got, ref) <= TOL[dn], relerr(got, ref)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', MS)
+def test_golden_all_ops(dev, golden_sym, dn, M):
+    """committed fixtures from the real reference"""
+    g, k = golden_sym, f'{dn}_M{M}_'
+    mat, vec, inp = t(g[k + 'mat'], dev), t(g[k + 'vec'], dev), t(g[k + 'inp'], dev)
+    S = N().sym
+    ex = M <= 4
+    check(S.sym_solve(mat, vec), g[k + 'solve'], dn, ex)
+    check(S.sym_matvec(mat, vec), g[k + 'matvec'], dn, True)
+    check(S.sym_addmatvec(inp, mat, vec), g[k + 'addmatvec'], dn, True)
+    check(S.sym_submatvec(inp, mat, vec), g[k + 'submatvec'], dn, True)
+    check(S.sym_invert(mat), g[k + 'invert'], dn, ex)
+    check(S.sym_invert(mat, diag=True), g[k + 'invert_diag'], dn, ex)
+    check(S.sym_det(mat), g[k + 'det'], dn, ex)
+    check(S.sym_to_full(mat), g[k + 'to_full'], dn, True)
+    check(S.sym_outer(vec), g[k + 'outer'], dn, True)
+    if M >= 2:
+        imat = t(g[k + 'mat_indef'], dev)
+        check(S.sym_solve(imat, vec), g[k + 'solve_indef'], dn, ex)
+        check(S.sym_invert(imat), g[k + 'invert_indef'], dn, ex)
+        check(S.sym_solve(mat[:, :M].contiguous(), vec), g[k + 'solve_diag'], dn, True)
+        check(S.sym_matvec(mat[:, :M].contiguous(), vec), g[k + 'matvec_diag'], dn, True)
+        check(S.sym_solve(mat[:, :1].contiguous(), vec), g[k + 'solve_scal'], dn, True)
+        check(S.sym_matvec(mat[:, :1].contiguous(), vec), g[k + 'matvec_scal'], dn, True)
+    if M > 2:
+        full = t(g[k + 'to_full'].reshape(len(g[k + 'mat']), M * M), dev)
+        check(S.sym_solve(full, vec), g[k + 'solve'], dn, False)
+        check(S.sym_matvec(full, vec), g[k + 'matvec'], dn, False)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('kd', [(1, 1), (2, 2), (3, 3), (3, 2), (4, 4), (2, 3)])
+def test_golden_matmul(dev, golden_sym, dn, kd):
+    g, k = golden_sym, f'{dn}_k{kd[0]}_d{kd[1]}_'
+    check(N().sym.sym_matmul(t(g[k + 'j'], dev), t(g[k + 'h'], dev)), g[k + 'matmul'], dn, True)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', MS)
+@pytest.mark.parametrize('n', [1, 63, 257, 5000])
+def test_vs_oracle_sizes(dev, oracle, dn, M, n):
+    """seeded inputs, ragged sizes (tile tails), tiled AoS path"""
+    if M > 8 and n > 1000:
+        n = 700
+    mat, vec = spd_np(n, M, np.float32 if dn == 'f32' else np.float64, 100 * M + n)
+    S = N().sym
+    ex = M <= 4
+    check(S.sym_solve(t(mat, dev), t(vec, dev)), oracle.sym_solve(mat, vec), dn, ex)
+    check(S.sym_matvec(t(mat, dev), t(vec, dev)), oracle.sym_matvec(mat, vec), dn, True)
+    check(S.sym_invert(t(mat, dev)), oracle.sym_invert(mat), dn, ex)
+    check(S.sym_invert(t(mat, dev), diag=True), oracle.sym_invert(mat, diag=True), dn, ex)
+    check(S.sym_det(t(mat, dev)), oracle.sym_det(mat), dn, ex)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [2, 3, 4, 6, 8, 12])
+def test_layouts(dev, oracle, dn, M):
+    """channel-first (SoA) fields, two-level batches, broadcast, misaligned views, out="""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    K = M * (M + 1) // 2
+    B, X, Y = 3, 17, 9
+    mat, vec = spd_np(B * X * Y, M, dtype, 7 + M)
+    ref = oracle.sym_solve(mat, vec).reshape(B, X, Y, M)
+    refmv = oracle.sym_matvec(mat, vec).reshape(B, X, Y, M)
+    ex = M <= 4
+    S = N().sym
+    mat4, vec4 = t(mat, dev).reshape(B, X, Y, K), t(vec, dev).reshape(B, X, Y, M)
+    # (B, C, X, Y) channel-first storage viewed channel-last: no copy, two batch levels
+    mat_cf = mat4.movedim(-1, 1).contiguous().movedim(1, -1)
+    vec_cf = vec4.movedim(-1, 1).contiguous().movedim(1, -1)
+    assert not mat_cf.is_contiguous()
+    check(S.sym_solve(mat_cf, vec_cf), ref, dn, ex)
+    check(S.sym_matvec(mat_cf, vec4), refmv, dn, True)          # mixed layouts
+    # channel-first output buffer through out=
+    out_cf = torch.empty(B, M, X, Y, dtype=vec4.dtype, device=dev).movedim(1, -1)
+    r = S.sym_solve(mat_cf, vec_cf, out=out_cf)
+    assert r.data_ptr() == out_cf.data_ptr()
+    check(out_cf, ref, dn, ex)
+    # pure SoA: (K, n).T
+    mat_soa = t(mat, dev).t().contiguous().t()
+    vec_soa = t(vec, dev).t().contiguous().t()
+    check(S.sym_solve(mat_soa, vec_soa), ref.reshape(-1, M), dn, ex)
+    # broadcast: one matrix against many vectors, and (1, X, 1, K) against (B, X, Y, M)
+    ref_b = oracle.sym_solve(np.broadcast_to(mat[:1], (len(vec), K)), vec)
+    check(S.sym_solve(t(mat[0], dev), t(vec, dev)), ref_b, dn, ex)
+    mp = mat.reshape(B, X, Y, K)[:1, :, :1]
+    ref_p = oracle.sym_solve(np.broadcast_to(mp, (B, X, Y, K)), vec.reshape(B, X, Y, M))
+    check(S.sym_solve(t(mp, dev), vec4), ref_p, dn, ex)
+    # misaligned base pointer (slice off one record) and strided batch
+    check(S.sym_solve(t(mat, dev)[1:], t(vec, dev)[1:]), ref.reshape(-1, M)[1:], dn, ex)
+    check(S.sym_solve(t(mat, dev)[::2], t(vec, dev)[::2]), ref.reshape(-1, M)[::2], dn, ex)
+    # a view with three genuine stride levels (materialised by the facade)
+    big = torch.zeros(B, 2, X, 2, Y, K, dtype=mat4.dtype, device=dev)
+    big[:, 0, :, 0] = mat4
+    check(S.sym_solve(big[:, 0, :, 0], vec4), ref, dn, ex)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [3, 4, 6, 12])
+def test_inplace_and_eps_and_dtype(dev, oracle, dn, M):
+    dtype = np.float32 if dn == 'f32' else np.float64
+    n = 1000
+    mat, vec = spd_np(n, M, dtype, 31 + M)
+    inp = np.random.default_rng(5).standard_normal((n, M)).astype(dtype)
+    S = N().sym
+    ex = M <= 4
+    v = t(vec, dev)
+    r = S.sym_solve_(t(mat, dev), v)
+    assert r.data_ptr() == v.data_ptr()
+    check(v, oracle.sym_solve(mat, vec), dn, ex)
+    m = t(mat, dev)
+    r = S.sym_invert_(m)
+    assert r.data_ptr() == m.data_ptr()
+    check(m, oracle.sym_invert(mat), dn, ex)
+    i = t(inp, dev)
+    S.sym_addmatvec_(i, t(mat, dev), t(vec, dev))
+    check(i, oracle.sym_matvec(mat, vec, inp, +1), dn, True)
+    i = t(inp, dev)
+    S.sym_submatvec_(i, t(mat, dev), t(vec, dev))
+    check(i, oracle.sym_matvec(mat, vec, inp, -1), dn, True)
+    # eps: documented intent = add to the diagonal (last value repeated)
+    eps = [0.5, 0.25]
+    e = np.array((eps + [eps[-1]] * M)[:M], dtype)
+    mat_e = mat.copy()
+    mat_e[:, :M] += e
+    check(S.sym_solve(t(mat, dev), t(vec, dev), eps=eps), oracle.sym_solve(mat_e, vec), dn, ex)
+    mat_s = mat.copy()
+    mat_s[:, :M] += dtype(0.125)
+    check(S.sym_solve(t(mat, dev), t(vec, dev), eps=0.125), oracle.sym_solve(mat_s, vec), dn, ex)
+    # dtype= : computation dtype
+    if dn == 'f32':
+        r = S.sym_solve(t(mat, dev), t(vec, dev), dtype=torch.float64)
+        assert r.dtype == torch.float64
+        check(r, oracle.sym_solve(mat.astype(np.float64), vec.astype(np.float64)), 'f64', ex)
+
+
+def test_empty_and_errors(dev):
+    S = N().sym
+    r = S.sym_solve(torch.zeros(0, 10, device=dev), torch.zeros(0, 4, device=dev))
+    assert r.shape == (0, 4)
+    assert S.sym_invert(torch.zeros(3, 0, 6, device=dev)).shape == (3, 0, 6)
+    with pytest.raises(ValueError):
+        S.sym_solve(torch.zeros(5, 7, device=dev), torch.zeros(5, 4, device=dev))
+    with pytest.raises(ValueError):
+        S.sym_invert(torch.zeros(5, 7, device=dev))
+    with pytest.raises(TypeError):
+        S.sym_solve(torch.zeros(5, 10, device=dev, dtype=torch.half), torch.zeros(5, 4, device=dev, dtype=torch.half))
+    with pytest.raises(ValueError):
+        S.sym_solve(torch.zeros(5, 17 * 9, device=dev), torch.zeros(5, 17, device=dev))
+    # singular input -> inf/nan like the reference, no error
+    r = S.sym_solve(torch.zeros(4, 10, device=dev), torch.ones(4, 4, device=dev))
+    assert not torch.isfinite(r).any()
+
+
+@pytest.mark.parametrize('M,n', [(4, 20_000_000), (6, 10_000_000), (3, 5_000_000)])
+def test_large_roundtrip_properties(dev, M, n):
+    """full-size style checks that need no oracle: solve(A, A v) == v, A inv(A) == I
+    (through matvec), bit-reproducibility, and sampled agreement with the oracle."""
+    import oracle as O
+    S = N().sym
+    g = torch.Generator(device=dev).manual_seed(99)
+    G = torch.randn(n, M, M, device=dev, generator=g)
+    A = G @ G.transpose(-1, -2) / M + torch.eye(M, device=dev)
+    iu = [(i, j) for i in range(M) for j in range(i + 1, M)]
+    mat = torch.stack([A[:, i, i] for i in range(M)] + [A[:, i, j] for i, j in iu], -1).contiguous()
+    del G, A
+    v = torch.randn(n, M, device=dev, generator=g)
+    y = S.sym_matvec(mat, v)
+    x = S.sym_solve(mat, y)
+    err = ((x - v).abs().amax() / v.abs().amax()).item()
+    assert err < 2e-5, err     # cond <= ~10, fp32
+    x2 = S.sym_solve(mat, y)
+    assert torch.equal(x, x2)
+    # linearity: solve(A, 2y) == 2 solve(A, y) exactly (power-of-two scaling)
+    assert torch.equal(S.sym_solve(mat, 2 * y), 2 * x)
+    # sampled oracle agreement at scattered offsets, incl. the last (partial) tile
+    idx = torch.cat([torch.arange(0, 4096), torch.arange(n // 2, n // 2 + 4096), torch.arange(n - 777, n)]).to(dev)
+    ref = O.sym_solve(mat[idx].cpu().numpy(), y[idx].cpu().numpy())
+    got = x[idx].cpu().numpy()
+    if M <= 4:
+        assert np.array_equal(got, ref)
+    else:
+        assert relerr(got, ref) <= 1e-6
+    inv = S.sym_invert(mat)
+    e = S.sym_matvec(inv, y)            # inv(A) (A v) == v
+    assert ((e - v).abs().amax() / v.abs().amax()).item() < 2e-5

@@ -1,0 +1,128 @@
+"""Pin the CPU oracle to golden vectors produced by the real reference
+(tests/golden/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+from conftest import TOL, relerr
+
+MS = (1, 2, 3, 4, 5, 6, 7, 8, 12, 16)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', MS)
+def test_sym_family(oracle, golden_sym, dn, M):
+    g, k = golden_sym, f'{dn}_M{M}_'
+    mat, vec, inp = g[k + 'mat'], g[k + 'vec'], g[k + 'inp']
+    got = {
+        'solve': oracle.sym_solve(mat, vec),
+        'matvec': oracle.sym_matvec(mat, vec),
+        'addmatvec': oracle.sym_matvec(mat, vec, inp, +1),
+        'submatvec': oracle.sym_matvec(mat, vec, inp, -1),
+        'invert': oracle.sym_invert(mat),
+        'invert_diag': oracle.sym_invert(mat, diag=True),
+        'det': oracle.sym_det(mat),
+        'to_full': oracle.sym_to_full(mat),
+        'outer': oracle.sym_outer(vec),
+    }
+    exact = {'matvec', 'addmatvec', 'submatvec', 'to_full', 'outer'}
+    for name, val in got.items():
+        ref = g[k + name]
+        assert val.shape == ref.shape and val.dtype == ref.dtype
+        if M <= 4 or name in exact:
+            # closed forms follow the reference's operation order: bit-identical
+            assert np.array_equal(val, ref), (name, relerr(val, ref))
+        else:
+            # M > 4: the reference calls LAPACK LU; same algorithm, different summation order
+            assert relerr(val, ref) <= TOL[dn], name
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', MS[1:])
+def test_sym_indefinite(oracle, golden_sym, dn, M):
+    g, k = golden_sym, f'{dn}_M{M}_'
+    s = oracle.sym_solve(g[k + 'mat_indef'], g[k + 'vec'])
+    i = oracle.sym_invert(g[k + 'mat_indef'])
+    if M <= 4:
+        assert np.array_equal(s, g[k + 'solve_indef']) and np.array_equal(i, g[k + 'invert_indef'])
+    else:
+        assert relerr(s, g[k + 'solve_indef']) <= TOL[dn]
+        assert relerr(i, g[k + 'invert_indef']) <= TOL[dn]
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', MS)
+def test_sym_kinds(oracle, golden_sym, dn, M):
+    g, k = golden_sym, f'{dn}_M{M}_'
+    mat, vec = g[k + 'mat'], g[k + 'vec']
+    if M > 1:   # for M == 1 every kind coincides with the compact reading
+        assert np.array_equal(oracle.sym_solve(mat[:, :M], vec), g[k + 'solve_diag'])
+        assert np.array_equal(oracle.sym_matvec(mat[:, :M], vec), g[k + 'matvec_diag'])
+        assert np.array_equal(oracle.sym_solve(mat[:, :1], vec), g[k + 'solve_scal'])
+        assert np.array_equal(oracle.sym_matvec(mat[:, :1], vec), g[k + 'matvec_scal'])
+    if M > 2:
+        full = g[k + 'to_full'].reshape(len(mat), M * M)
+        assert relerr(oracle.sym_solve(full, vec), g[k + 'solve']) <= TOL[dn]
+        assert relerr(oracle.sym_matvec(full, vec), g[k + 'matvec']) <= TOL[dn]
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('kd', [(1, 1), (2, 2), (3, 3), (3, 2), (4, 4), (2, 3)])
+def test_sym_matmul(oracle, golden_sym, dn, kd):
+    g, k = golden_sym, f'{dn}_k{kd[0]}_d{kd[1]}_'
+    assert np.array_equal(oracle.sym_matmul(g[k + 'j'], g[k + 'h']), g[k + 'matmul'])
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('n', MS)
+def test_batched(oracle, golden_batched, dn, n):
+    g, k = golden_batched, f'{dn}_n{n}_'
+    a, v = g[k + 'a'], g[k + 'v']
+    assert relerr(oracle.batch_inv(a), g[k + 'inv']) <= TOL[dn]
+    assert relerr(oracle.batch_det(a), g[k + 'det']) <= TOL[dn]
+    assert relerr(oracle.batch_matvec(a, v), g[k + 'matvec']) <= TOL[dn]
+    if n in (2, 3):  # the TorchScript closed forms, incl. the det perturbation: bit-identical
+        assert np.array_equal(oracle.batch_inv(a, closed=True), g[k + 'inv_ts'])
+        assert np.array_equal(oracle.batch_det(a, closed=True), g[k + 'det_ts'])
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_batched_rect(oracle, golden_batched, dn):
+    g = golden_batched
+    assert relerr(oracle.batch_matvec(g[dn + '_rect_a'], g[dn + '_rect_v']), g[dn + '_rect_matvec']) <= TOL[dn]
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('size', [1, 63, 64, 65, 4097, 20011])
+@pytest.mark.parametrize('nn', ['nan0', 'nan1', 'nanall'])
+def test_reduce_full(oracle, golden_reduce, dn, size, nn):
+    g, k = golden_reduce, f'{dn}_{size}_{nn}_'
+    x = g[k + 'x']
+    fin = x[np.isfinite(x)]
+    scale = max(float(np.abs(fin).sum()), 1e-30)
+    for op in ('nansum', 'sum'):
+        r, e = oracle.reduce(op, x), g[k + op]
+        assert (np.isnan(r) and np.isnan(e)) or r == e or abs(float(r) - float(e)) <= TOL[dn] * scale
+    r, e = oracle.reduce('nansum', x, out_f64=True), g[k + 'nansum64']
+    assert (np.isnan(r) and np.isnan(e)) or r == e or abs(float(r) - float(e)) <= 1e-12 * scale
+    for op in ('nanmax', 'nanmin', 'max', 'min'):
+        r, e = oracle.reduce(op, x), g[k + op]
+        assert (np.isnan(r) and np.isnan(e)) or r == e, op
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_reduce_dims(oracle, golden_reduce, dn):
+    g = golden_reduce
+    x = g[dn + '_nd_x']
+    for dim, name in ((0, 'd0'), (1, 'd1'), (2, 'd2'), (-1, 'dm1'), ((0, 2), 'd02'), ((1, 2), 'd12')):
+        r = oracle.reduce('nansum', x, dim)
+        e = g[f'{dn}_nd_nansum_{name}']
+        assert r.shape == e.shape and relerr(r, e) <= TOL[dn]
+        rk = oracle.reduce('nansum', x, dim, keepdim=True)
+        assert rk.shape == g[f'{dn}_nd_nansum_keep_{name}'].shape
+        s = oracle.reduce('sum', x, dim)
+        es = g[f'{dn}_nd_sum_{name}']
+        assert np.array_equal(np.isnan(s), np.isnan(es))
+        assert relerr(np.nan_to_num(s), np.nan_to_num(es)) <= TOL[dn]
+
+
+def test_reduce_empty(oracle, golden_reduce):
+    assert oracle.reduce('nansum', np.zeros(0, np.float32)) == golden_reduce['f32_empty_nansum'] == 0
