@@ -43,23 +43,23 @@ def parse():
     return p.parse_args()
 
 
-def spd_compact(n, M, dtype, device, seed, chunk=5_000_000):
-    """A = G G^T / M + I packed diagonal-first, generated on device in chunks."""
+def spd_compact(n, M, dtype, device, seed, chunk=1 << 22):
+    """A = G G^T / M + I packed diagonal-first, generated on device in chunks
+    with element-wise ops only (rocBLAS batched GEMM faults on batch counts of ~1e7)."""
     import torch
     K = M * (M + 1) // 2
     g = torch.Generator(device=device).manual_seed(seed)
     mat = torch.empty(n, K, dtype=dtype, device=device)
-    iu = [(i, j) for i in range(M) for j in range(i + 1, M)]
-    eye = torch.eye(M, device=device, dtype=torch.float32)
+    pairs = [(i, i) for i in range(M)] + [(i, j) for i in range(M) for j in range(i + 1, M)]
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
-        G = torch.randn(hi - lo, M, M, device=device, generator=g)
-        A = G @ G.transpose(-1, -2) / M + eye
-        for c in range(M):
-            mat[lo:hi, c] = A[:, c, c]
-        for c, (i, j) in enumerate(iu):
-            mat[lo:hi, M + c] = A[:, i, j]
-        del G, A
+        G = torch.randn(M, M, hi - lo, device=device, generator=g)
+        for c, (i, j) in enumerate(pairs):
+            a = (G[i] * G[j]).sum(0) / M
+            if i == j:
+                a += 1
+            mat[lo:hi, c] = a
+        del G
     vec = torch.randn(n, M, device=device, generator=g).to(dtype)
     return mat, vec
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Condense a rocprofv3 --kernel-trace --stats CSV directory into a short, readable
+summary (kernel names trimmed) for profiles/.  usage: summarize_prof.py <dir> <out.md> [title]"""
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def trim(name):
+    name = re.sub(r'\(.*', '', name)
+    name = name.replace('void ', '').replace('nfm::', '')
+    return name[:110]
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    title = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(d)
+    stats = glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)
+    trace = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)
+    lines = [f'# {title}', '', 'source: `rocprofv3 --kernel-trace --stats --output-format csv` '
+             '(per-kernel durations in ns; names trimmed)', '']
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        lines += ['| kernel | calls | avg ns | min ns | max ns | % |', '|---|---|---|---|---|---|']
+        for r in rows[:12]:
+            lines.append(f"| `{trim(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | "
+                         f"{r['MaxNs']} | {float(r['Percentage']):.2f} |")
+    if trace:
+        rows = [r for r in csv.DictReader(open(trace[0])) if 'nfm::' in r['Kernel_Name']]
+        seen = {}
+        for r in rows:
+            k = trim(r['Kernel_Name'])
+            seen.setdefault(k, r)
+        lines += ['', '| nfm kernel | VGPR | SGPR | LDS B/block | scratch | workgroup | grid |', '|---|---|---|---|---|---|---|']
+        for k, r in seen.items():
+            lines.append(f"| `{k}` | {r['VGPR_Count']} | {r['SGPR_Count']} | {r['LDS_Block_Size']} | {r['Scratch_Size']} | "
+                         f"{r['Workgroup_Size_X']} | {r['Grid_Size_X']}x{r['Grid_Size_Y']} |")
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:14]))
+
+
+if __name__ == '__main__':
+    main()

@@ -201,13 +201,8 @@ def test_large_roundtrip_properties(dev, M, n):
     (through matvec), bit-reproducibility, and sampled agreement with the oracle."""
     import oracle as O
     S = N().sym
-    g = torch.Generator(device=dev).manual_seed(99)
-    G = torch.randn(n, M, M, device=dev, generator=g)
-    A = G @ G.transpose(-1, -2) / M + torch.eye(M, device=dev)
-    iu = [(i, j) for i in range(M) for j in range(i + 1, M)]
-    mat = torch.stack([A[:, i, i] for i in range(M)] + [A[:, i, j] for i, j in iu], -1).contiguous()
-    del G, A
-    v = torch.randn(n, M, device=dev, generator=g)
+    from bench import spd_compact     # element-wise generator (no batched GEMM)
+    mat, v = spd_compact(n, M, torch.float32, dev, 99)
     y = S.sym_matvec(mat, v)
     x = S.sym_solve(mat, y)
     err = ((x - v).abs().amax() / v.abs().amax()).item()
