@@ -257,10 +257,10 @@ inline BigArgs big_args(const nfm_operand *a, const nfm_operand *b, const nfm_op
 {
     BigArgs g;
     nfm_operand none = {nullptr, 0, 0, 0, 0};
-    g.a = make_opnd(a ? a : &none, false);
-    g.b = make_opnd(b ? b : &none, false);
-    g.c = make_opnd(c ? c : &none, false);
-    g.out = make_opnd(out ? out : &none, false);
+    g.a = make_opnd(a ? a : &none, 0);
+    g.b = make_opnd(b ? b : &none, 0);
+    g.c = make_opnd(c ? c : &none, 0);
+    g.out = make_opnd(out ? out : &none, 0);
     g.n_inner = ni;
     g.N = N;
     g.N2 = N2;

@@ -272,7 +272,25 @@ inline bool tile_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_
     return true;
 }
 
-inline Opnd make_opnd(const nfm_operand *op, bool tiled)
+// Can the operand be moved with one packed 4/8/16-byte access per lane?  Records back
+// to back along the inner batch level, every record (and every outer slab) aligned to
+// the record size.
+inline bool vec_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_outer, size_t elem)
+{
+    if (op->ptr == nullptr) return false;
+    const size_t rb = (size_t)C * elem;
+    if (reinterpret_cast<uintptr_t>(op->ptr) % rb != 0) return false;
+    if (op->stride_inner != C) return false;
+    if (n_outer > 1 && (op->stride_outer % C) != 0) return false;
+    if (rows > 1) {
+        if (op->stride_row != cols || op->stride_col != 1) return false;
+    } else if (C > 1 && op->stride_col != 1) {
+        return false;
+    }
+    return true;
+}
+
+inline Opnd make_opnd(const nfm_operand *op, int tiled)
 {
     Opnd d;
     d.ptr = static_cast<char *>(op->ptr);
@@ -280,7 +298,7 @@ inline Opnd make_opnd(const nfm_operand *op, bool tiled)
     d.si = op->stride_inner;
     d.sr = op->stride_row;
     d.sc = op->stride_col;
-    d.tiled = tiled ? 1 : 0;
+    d.tiled = tiled;
     return d;
 }
 
