@@ -162,6 +162,63 @@ int nfm_reduce_all(int dtype, int op, int out_dtype, int64_t n, const void *x, v
 int nfm_reduce_dim(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner,
                    const void *x, void *out, int64_t *idx, void *stream);
 
+/* ------------------------------------------------------------------- qr ---- */
+/* Real dtypes.  Multi-output routines write ONE packed, contiguous output record per
+ * matrix into `out` (n_outer * n_inner records, batch-major); the layout of the record
+ * is given with each entry point.  Inputs are ordinary strided operands. */
+
+#define NFM_SIDE_LEFT 0
+#define NFM_SIDE_RIGHT 1
+#define NFM_SIDE_BOTH 2
+
+/* c = x / r, s = -y / r, r = sqrt(x^2 + y^2); r == 0 -> (1, 0).  `givens` `_impl/qr.py:326-369`.
+ * x, y: one element per batch entry; out record: [c, s]. */
+int nfm_qr_givens(int dtype, int64_t n_outer, int64_t n_inner, const nfm_operand *x,
+                  const nfm_operand *y, void *out, void *stream);
+
+/* IN PLACE on `a` (N x N): rotate rows (left), columns (right) or both i and j.
+ * `givens_apply_` `_impl/qr.py:370-429`.  c, s: N components per batch entry (stride_col 0 =
+ * one coefficient for the whole row/column, the usual case). */
+int nfm_qr_givens_apply(int dtype, int N, int side, int i, int j, int64_t n_outer, int64_t n_inner,
+                        const nfm_operand *a, const nfm_operand *c, const nfm_operand *s, void *stream);
+
+/* Householder vector of x (length N) reflecting onto component `basis`, and the projection
+ * alpha.  `householder_` `_impl/qr.py:55-69`.  out record: [u (N) | alpha]. */
+int nfm_qr_householder(int dtype, int N, int basis, int64_t n_outer, int64_t n_inner,
+                       const nfm_operand *x, void *out, void *stream);
+
+/* IN PLACE on `a` (N x N): apply P = I - 2 u u^T, u of length m acting on the trailing m
+ * rows (left) / columns (right).  One reflector of `householder_apply_` `_impl/qr.py:72-106`. */
+int nfm_qr_householder_apply(int dtype, int N, int m, int side, int64_t n_outer, int64_t n_inner,
+                             const nfm_operand *a, const nfm_operand *u, void *stream);
+
+/* Householder reduction to Hessenberg form (sym == 0: `hessenberg_` `_impl/qr.py:117-141`) or
+ * of a symmetric matrix to tridiagonal form reading only the `upper` / lower triangle
+ * (sym != 0: `hessenberg_sym_upper_/lower_` `:280-323`; output filled symmetric).
+ * out record: [H (N*N row-major) | with_u: (N-2) reflectors, reflector k in a slot of N-1
+ * elements, its N-1-k entries first, zero padded]. */
+int nfm_qr_hessenberg(int dtype, int N, int sym, int upper, int with_u, int64_t n_outer,
+                      int64_t n_inner, const nfm_operand *a, void *out, void *stream);
+
+/* Q, R of an upper-Hessenberg matrix by N-1 Givens rotations, `qr_hessenberg_`
+ * `_impl/qr.py:432-454`.  out record: [Q (N*N) | R (N*N)]. */
+int nfm_qr_qr_hessenberg(int dtype, int N, int64_t n_outer, int64_t n_inner, const nfm_operand *h,
+                         void *out, void *stream);
+
+/* One QR step H <- R Q (and U <- U Q when u != NULL), `rq_hessenberg_` `_impl/qr.py:457-530`.
+ * sym != 0: the tridiagonal shortcut of the reference; sym == 0: the true R Q for any
+ * Hessenberg input (quirk Q8 fixed).  out record: [H' (N*N) | U' (N*N) if u]. */
+int nfm_qr_rq_hessenberg(int dtype, int N, int sym, int64_t n_outer, int64_t n_inner,
+                         const nfm_operand *h, const nfm_operand *u, void *out, void *stream);
+
+/* Eigenvalues (unsorted, deflation order) and optionally eigenvectors of symmetric matrices:
+ * tridiagonalisation + explicit QR with Wilkinson shifts, `eig_sym` `qr.py:30-100`,
+ * `_fwd_eig_sym` `_impl/qr.py:665-681`.  Convergence is judged per matrix with the
+ * reference's criterion (quirk Q9).  out record: [vals (N) | with_u: vecs (N*N row-major,
+ * eigenvectors in columns)]. */
+int nfm_qr_eig_sym(int dtype, int N, int upper, int with_u, int max_iter, double tol,
+                   int64_t n_outer, int64_t n_inner, const nfm_operand *a, void *out, void *stream);
+
 /* ------------------------------------------------------------------- misc ---- */
 
 const char *nfm_strerror(int code);

@@ -7,9 +7,10 @@ hand-written HIP in `libnfm_hip.so`, reached through the C ABI of include/nfm_hi
 There is no CPU path: importing works anywhere, calling needs the built library and
 GPU tensors.
 """
-from . import sym, batched, reduce, utils  # noqa: F401
+from . import sym, batched, reduce, qr, utils  # noqa: F401
 from .sym import *       # noqa: F401,F403
 from .batched import *   # noqa: F401,F403
+from .qr import *        # noqa: F401,F403
 # `reduce` shadows builtins (min, max, sum) exactly like the reference's star-import does
 # (`__init__.py:1-10`); keep them namespaced at package level as well.
 from ._lib import LIB_PATH, lib as _load_lib  # noqa: F401

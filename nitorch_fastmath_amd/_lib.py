@@ -14,6 +14,7 @@ MAT_SYM, MAT_DIAG, MAT_SCAL, MAT_FULL = 0, 1, 2, 3
 FLAG_TS_PERTURB = 1
 RED_NANSUM, RED_NANMAX, RED_NANMIN, RED_SUM, RED_MAX, RED_MIN, RED_NANCOUNT, RED_NANSUMSQ = range(8)
 MAX_DIM = 16
+SIDE = {'left': 0, 'right': 1, 'both': 2}
 
 
 class Operand(ctypes.Structure):
@@ -42,6 +43,14 @@ SIGNATURES = {
     'nfm_batch_matvec': [_i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_reduce_all': [_i, _i, _i, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
     'nfm_reduce_dim': [_i, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    'nfm_qr_givens': [_i, _i64, _i64, _op, _op, _vp, _vp],
+    'nfm_qr_givens_apply': [_i, _i, _i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
+    'nfm_qr_householder': [_i, _i, _i, _i64, _i64, _op, _vp, _vp],
+    'nfm_qr_householder_apply': [_i, _i, _i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_qr_hessenberg': [_i, _i, _i, _i, _i, _i64, _i64, _op, _vp, _vp],
+    'nfm_qr_qr_hessenberg': [_i, _i, _i64, _i64, _op, _vp, _vp],
+    'nfm_qr_rq_hessenberg': [_i, _i, _i, _i64, _i64, _op, _op, _vp, _vp],
+    'nfm_qr_eig_sym': [_i, _i, _i, _i, _i, ctypes.c_double, _i64, _i64, _op, _vp, _vp],
 }
 
 _lib = None

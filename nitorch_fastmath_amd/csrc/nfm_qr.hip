@@ -1,0 +1,543 @@
+// nfm_qr.hip -- Givens / Householder / Hessenberg / QR-algorithm entry points
+// (reference `qr.py`, `_impl/qr.py`).  Orders 1..8 run in registers through rec_kernel;
+// orders 9..16 run the same source with run-time loops (per-lane scratch arrays).
+// Multi-output routines write ONE packed output record per matrix (the facade hands out
+// views): eig_sym [vals | vecs], hessenberg [H | reflectors], qr_hessenberg [Q | R], ...
+#include "nfm_record_kernel.hpp"
+#include "nfm_qr_core.hpp"
+
+namespace nfm {
+
+constexpr int upack_len(int N) { return N > 2 ? (N - 2) * (N - 1) : 0; }
+
+struct QrParams {
+    int n;        // run-time order (generic kernels)
+    int upper;    // which triangle of a symmetric input holds the data
+    int sym;      // rq_hessenberg: tridiagonal shortcut
+    int basis;    // householder: component to reflect onto
+    int max_iter;
+    double tol;
+};
+
+// load an N x N record into a 2-D register matrix (optionally mirroring one triangle)
+template <typename T, int N>
+__device__ __forceinline__ void to_mat(const T (&r)[N * N], T (&a)[N][N], int mirror_upper)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (mirror_upper < 0) a[i][j] = r[i * N + j];
+            else if (mirror_upper) a[i][j] = (i <= j) ? r[i * N + j] : r[j * N + i];
+            else a[i][j] = (i >= j) ? r[i * N + j] : r[j * N + i];
+        }
+}
+
+template <typename T, int N, bool WITH_U>
+struct EigSymOp {
+    using RA = Rec<N, N>;
+    using RB = NoRec;
+    using RC = NoRec;
+    using RO = Rec<1, N + (WITH_U ? N * N : 0)>;
+    using Params = QrParams;
+    static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
+    static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
+                                                 T (&o)[RO::Cs], const Params &p)
+    {
+        T a[N][N], u[N][N];
+        to_mat<T, N>(r, a, p.upper);
+        qr::eig_sym1<T, N, WITH_U>(a, u, N, p.max_iter, p.tol);
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = a[i][i];
+        if constexpr (WITH_U) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[N + i * N + j] = u[i][j];
+        }
+    }
+};
+
+// SYM: hessenberg_sym (tridiagonalisation, output filled symmetric); else hessenberg
+template <typename T, int N, bool SYM, bool WITH_U>
+struct HessOp {
+    using RA = Rec<N, N>;
+    using RB = NoRec;
+    using RC = NoRec;
+    using RO = Rec<1, N * N + (WITH_U ? upack_len(N) : 0)>;
+    using Params = QrParams;
+    static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
+    static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
+                                                 T (&o)[RO::Cs], const Params &p)
+    {
+        T a[N][N], up[N][N];
+        if constexpr (SYM) {
+            to_mat<T, N>(r, a, p.upper);
+            qr::hessenberg_sym1<T, N, WITH_U>(a, N, up);
+        } else {
+            to_mat<T, N>(r, a, -1);
+            qr::hessenberg1<T, N, WITH_U>(a, N, up);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[i * N + j] = a[i][j];
+        if constexpr (WITH_U && N > 2) {
+#pragma unroll
+            for (int k = 0; k < N - 2; ++k)
+#pragma unroll
+                for (int c = 0; c < N - 1; ++c) o[N * N + k * (N - 1) + c] = (c < N - 1 - k) ? up[k][c] : T(0);
+        }
+    }
+};
+
+template <typename T, int N>
+struct QrHessOp {
+    using RA = Rec<N, N>;
+    using RB = NoRec;
+    using RC = NoRec;
+    using RO = Rec<1, 2 * N * N>;
+    using Params = QrParams;
+    static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
+    static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
+                                                 T (&o)[RO::Cs], const Params &)
+    {
+        T a[N][N], q[N][N];
+        to_mat<T, N>(r, a, -1);
+        qr::qr_hessenberg1<T, N>(a, q, N);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                o[i * N + j] = q[i][j];
+                o[N * N + i * N + j] = a[i][j];
+            }
+    }
+};
+
+template <typename T, int N, bool WITH_U>
+struct RqHessOp {
+    using RA = Rec<N, N>;
+    using RB = Rec<(WITH_U ? N : 0), (WITH_U ? N : 0)>;
+    using RC = NoRec;
+    using RO = Rec<1, N * N * (WITH_U ? 2 : 1)>;
+    using Params = QrParams;
+    static constexpr int TILE = pick_tile((RA::C + RB::C + RO::C) * (int)sizeof(T) + 48);
+    static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&ru)[RB::Cs], const T (&)[1],
+                                                 T (&o)[RO::Cs], const Params &p)
+    {
+        T a[N][N], u[N][N];
+        to_mat<T, N>(r, a, -1);
+        if constexpr (WITH_U) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) u[i][j] = ru[i * N + j];
+        }
+        qr::rq_step1<T, N, WITH_U>(a, u, N, N, p.sym != 0);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                o[i * N + j] = a[i][j];
+                if constexpr (WITH_U) o[N * N + i * N + j] = u[i][j];
+            }
+    }
+};
+
+template <typename T, int N>
+struct HouseholderOp {
+    using RA = Rec<1, N>;
+    using RB = NoRec;
+    using RC = NoRec;
+    using RO = Rec<1, N + 1>;
+    using Params = QrParams;
+    static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
+    static __device__ __forceinline__ void apply(const T (&x)[N], const T (&)[1], const T (&)[1], T (&o)[N + 1],
+                                                 const Params &p)
+    {
+        T u[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) u[i] = x[i];
+        const T alpha = qr::householder1<T, N>(u, N, p.basis);
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = u[i];
+        o[N] = alpha;
+    }
+};
+
+template <typename T>
+struct GivensOp {
+    using RA = Rec<1, 1>;
+    using RB = Rec<1, 1>;
+    using RC = NoRec;
+    using RO = Rec<1, 2>;
+    using Params = QrParams;
+    static constexpr int TILE = 256;
+    static __device__ __forceinline__ void apply(const T (&x)[1], const T (&y)[1], const T (&)[1], T (&o)[2],
+                                                 const Params &)
+    {
+        qr::givens1(x[0], y[0], o[0], o[1]);
+    }
+};
+
+// ---------------------------------------------------------------- generic (run-time n)
+enum { QG_EIG = 0, QG_EIG_U, QG_HESS, QG_HESS_U, QG_HESSSYM, QG_HESSSYM_U, QG_QR, QG_RQ, QG_RQ_U, QG_HH };
+
+template <typename T, int OP>
+__global__ __launch_bounds__(64) void qr_generic_kernel(Opnd a, Opnd b, T *__restrict__ out, int64_t out_rec,
+                                                        int64_t n_inner, QrParams p)
+{
+    constexpr int MX = NFM_MAX_DIM;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t o = blockIdx.y;
+    if (i >= n_inner) return;
+    const int n = p.n;
+    const T *pa = reinterpret_cast<const T *>(a.ptr) + o * a.so + i * a.si;
+    T *po = out + (o * n_inner + i) * out_rec;
+    T m[MX][MX], u[MX][MX];
+    if constexpr (OP == QG_HH) {
+        T x[MX];
+        for (int r = 0; r < n; ++r) x[r] = pa[r * a.sc];
+        const T alpha = qr::householder1<T, 0>(x, n, p.basis);
+        for (int r = 0; r < n; ++r) po[r] = x[r];
+        po[n] = alpha;
+        return;
+    } else {
+    const bool symin = OP == QG_EIG || OP == QG_EIG_U || OP == QG_HESSSYM || OP == QG_HESSSYM_U;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            int rr = r, cc = c;
+            if (symin && ((p.upper && r > c) || (!p.upper && r < c))) { rr = c; cc = r; }
+            m[r][c] = pa[rr * a.sr + cc * a.sc];
+        }
+    if constexpr (OP == QG_EIG || OP == QG_EIG_U) {
+        qr::eig_sym1<T, 0, OP == QG_EIG_U>(m, u, n, p.max_iter, p.tol);
+        for (int r = 0; r < n; ++r) po[r] = m[r][r];
+        if (OP == QG_EIG_U)
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c < n; ++c) po[n + r * n + c] = u[r][c];
+    } else if constexpr (OP == QG_HESS || OP == QG_HESS_U || OP == QG_HESSSYM || OP == QG_HESSSYM_U) {
+        constexpr bool WU = OP == QG_HESS_U || OP == QG_HESSSYM_U;
+        if constexpr (OP == QG_HESS || OP == QG_HESS_U) qr::hessenberg1<T, 0, WU>(m, n, u);
+        else qr::hessenberg_sym1<T, 0, WU>(m, n, u);
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) po[r * n + c] = m[r][c];
+        if (WU)
+            for (int k = 0; k < n - 2; ++k)
+                for (int c = 0; c < n - 1; ++c) po[n * n + k * (n - 1) + c] = (c < n - 1 - k) ? u[k][c] : T(0);
+    } else if constexpr (OP == QG_QR) {
+        qr::qr_hessenberg1<T, 0>(m, u, n);
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) {
+                po[r * n + c] = u[r][c];
+                po[n * n + r * n + c] = m[r][c];
+            }
+    } else { // QG_RQ, QG_RQ_U
+        if (OP == QG_RQ_U) {
+            const T *pb = reinterpret_cast<const T *>(b.ptr) + o * b.so + i * b.si;
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c < n; ++c) u[r][c] = pb[r * b.sr + c * b.sc];
+        }
+        qr::rq_step1<T, 0, OP == QG_RQ_U>(m, u, n, n, p.sym != 0);
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) {
+                po[r * n + c] = m[r][c];
+                if (OP == QG_RQ_U) po[n * n + r * n + c] = u[r][c];
+            }
+    }
+    }
+}
+
+// in-place rotations / reflections of strided matrices (any order <= 16)
+template <typename T>
+__global__ __launch_bounds__(256) void givens_apply_kernel(Opnd a, Opnd c, Opnd s, int64_t n_inner, int n, int gi,
+                                                           int gj, int side)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t o = blockIdx.y;
+    if (i >= n_inner) return;
+    T *pa = reinterpret_cast<T *>(a.ptr) + o * a.so + i * a.si;
+    const T *pc = reinterpret_cast<const T *>(c.ptr) + o * c.so + i * c.si;
+    const T *ps = reinterpret_cast<const T *>(s.ptr) + o * s.so + i * s.si;
+    if (side == 0 || side == 2)
+        for (int k = 0; k < n; ++k) {
+            T a0 = pa[gi * a.sr + k * a.sc], a1 = pa[gj * a.sr + k * a.sc];
+            qr::rot1(a0, a1, pc[k * c.sc], ps[k * s.sc]);
+            pa[gi * a.sr + k * a.sc] = a0;
+            pa[gj * a.sr + k * a.sc] = a1;
+        }
+    if (side == 1 || side == 2)
+        for (int k = 0; k < n; ++k) {
+            T a0 = pa[k * a.sr + gi * a.sc], a1 = pa[k * a.sr + gj * a.sc];
+            qr::rot1(a0, a1, pc[k * c.sc], ps[k * s.sc]);
+            pa[k * a.sr + gi * a.sc] = a0;
+            pa[k * a.sr + gj * a.sc] = a1;
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void householder_apply_kernel(Opnd a, Opnd u, int64_t n_inner, int n, int m,
+                                                                int side)
+{
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t o = blockIdx.y;
+    if (i >= n_inner) return;
+    T *pa = reinterpret_cast<T *>(a.ptr) + o * a.so + i * a.si;
+    const T *pu = reinterpret_cast<const T *>(u.ptr) + o * u.so + i * u.si;
+    const int k0 = n - m;
+    if (side == 0 || side == 2)
+        for (int c = 0; c < n; ++c) {
+            T d = T(0);
+            for (int r = 0; r < m; ++r) d += pu[r * u.sc] * pa[(k0 + r) * a.sr + c * a.sc];
+            for (int r = 0; r < m; ++r) pa[(k0 + r) * a.sr + c * a.sc] -= T(2) * (pu[r * u.sc] * d);
+        }
+    if (side == 1 || side == 2)
+        for (int r = 0; r < n; ++r) {
+            T d = T(0);
+            for (int c = 0; c < m; ++c) d += pa[r * a.sr + (k0 + c) * a.sc] * pu[c * u.sc];
+            for (int c = 0; c < m; ++c) pa[r * a.sr + (k0 + c) * a.sc] -= T(2) * (d * pu[c * u.sc]);
+        }
+}
+
+// ------------------------------------------------------------------------- dispatch
+#define NFM_QR_CASE(Nv, ...)  \
+    case Nv: {                \
+        constexpr int N = Nv; \
+        __VA_ARGS__;          \
+    } break;
+#define NFM_QR_SWITCH8(Nexpr, ...)   \
+    switch (Nexpr) {                 \
+        NFM_QR_CASE(1, __VA_ARGS__)  \
+        NFM_QR_CASE(2, __VA_ARGS__)  \
+        NFM_QR_CASE(3, __VA_ARGS__)  \
+        NFM_QR_CASE(4, __VA_ARGS__)  \
+        NFM_QR_CASE(5, __VA_ARGS__)  \
+        NFM_QR_CASE(6, __VA_ARGS__)  \
+        NFM_QR_CASE(7, __VA_ARGS__)  \
+        NFM_QR_CASE(8, __VA_ARGS__)  \
+    default:                         \
+        break;                       \
+    }
+
+template <typename T, int OP>
+static int qr_generic_launch(const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no,
+                             int64_t ni, const QrParams &p, void *stream)
+{
+    if (no == 0 || ni == 0) return NFM_OK;
+    nfm_operand none = {nullptr, 0, 0, 0, 0};
+    dim3 grid((unsigned)((ni + 63) / 64), (unsigned)no, 1);
+    hipLaunchKernelGGL((qr_generic_kernel<T, OP>), grid, dim3(64), 0, static_cast<hipStream_t>(stream),
+                       make_opnd(a, 0), make_opnd(b ? b : &none, 0), static_cast<T *>(out), out_rec, ni, p);
+    return launch_status();
+}
+
+// the packed output record is a plain contiguous (n_outer * n_inner, rec) buffer
+static nfm_operand packed_out(void *out, int64_t rec, int64_t ni)
+{
+    nfm_operand o = {out, ni * rec, rec, 0, 1};
+    return o;
+}
+
+template <typename T>
+static int eig_sym_t(int N, int with_u, int64_t no, int64_t ni, const nfm_operand *a, void *out, const QrParams &p,
+                     void *stream)
+{
+    const int64_t rec = N + (with_u ? N * N : 0);
+    nfm_operand o = packed_out(out, rec, ni);
+    if (with_u) {
+        NFM_QR_SWITCH8(N, return (rec_launch<T, EigSymOp<T, N, true>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+        return qr_generic_launch<T, QG_EIG_U>(a, nullptr, out, rec, no, ni, p, stream);
+    }
+    NFM_QR_SWITCH8(N, return (rec_launch<T, EigSymOp<T, N, false>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+    return qr_generic_launch<T, QG_EIG>(a, nullptr, out, rec, no, ni, p, stream);
+}
+
+template <typename T>
+static int hess_t(int N, int sym, int with_u, int64_t no, int64_t ni, const nfm_operand *a, void *out,
+                  const QrParams &p, void *stream)
+{
+    const int64_t rec = N * N + (with_u ? upack_len(N) : 0);
+    nfm_operand o = packed_out(out, rec, ni);
+    if (sym && with_u) {
+        NFM_QR_SWITCH8(N, return (rec_launch<T, HessOp<T, N, true, true>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+        return qr_generic_launch<T, QG_HESSSYM_U>(a, nullptr, out, rec, no, ni, p, stream);
+    } else if (sym) {
+        NFM_QR_SWITCH8(N, return (rec_launch<T, HessOp<T, N, true, false>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+        return qr_generic_launch<T, QG_HESSSYM>(a, nullptr, out, rec, no, ni, p, stream);
+    } else if (with_u) {
+        NFM_QR_SWITCH8(N, return (rec_launch<T, HessOp<T, N, false, true>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+        return qr_generic_launch<T, QG_HESS_U>(a, nullptr, out, rec, no, ni, p, stream);
+    }
+    NFM_QR_SWITCH8(N, return (rec_launch<T, HessOp<T, N, false, false>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+    return qr_generic_launch<T, QG_HESS>(a, nullptr, out, rec, no, ni, p, stream);
+}
+
+template <typename T>
+static int qr_hess_t(int N, int64_t no, int64_t ni, const nfm_operand *a, void *out, const QrParams &p, void *stream)
+{
+    const int64_t rec = 2 * N * N;
+    nfm_operand o = packed_out(out, rec, ni);
+    NFM_QR_SWITCH8(N, return (rec_launch<T, QrHessOp<T, N>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+    return qr_generic_launch<T, QG_QR>(a, nullptr, out, rec, no, ni, p, stream);
+}
+
+template <typename T>
+static int rq_hess_t(int N, int64_t no, int64_t ni, const nfm_operand *a, const nfm_operand *u, void *out,
+                     const QrParams &p, void *stream)
+{
+    const int64_t rec = N * N * (u ? 2 : 1);
+    nfm_operand o = packed_out(out, rec, ni);
+    if (u) {
+        NFM_QR_SWITCH8(N, return (rec_launch<T, RqHessOp<T, N, true>>(a, u, nullptr, &o, no, ni, p, stream)))
+        return qr_generic_launch<T, QG_RQ_U>(a, u, out, rec, no, ni, p, stream);
+    }
+    NFM_QR_SWITCH8(N, return (rec_launch<T, RqHessOp<T, N, false>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+    return qr_generic_launch<T, QG_RQ>(a, nullptr, out, rec, no, ni, p, stream);
+}
+
+template <typename T>
+static int householder_t(int N, int64_t no, int64_t ni, const nfm_operand *x, void *out, const QrParams &p,
+                         void *stream)
+{
+    const int64_t rec = N + 1;
+    nfm_operand o = packed_out(out, rec, ni);
+    NFM_QR_SWITCH8(N, return (rec_launch<T, HouseholderOp<T, N>>(x, nullptr, nullptr, &o, no, ni, p, stream)))
+    return qr_generic_launch<T, QG_HH>(x, nullptr, out, rec, no, ni, p, stream);
+}
+
+static QrParams mkparams(int n, int upper, int sym, int basis, int max_iter, double tol)
+{
+    QrParams p;
+    p.n = n;
+    p.upper = upper;
+    p.sym = sym;
+    p.basis = basis;
+    p.max_iter = max_iter;
+    p.tol = tol;
+    return p;
+}
+
+} // namespace nfm
+
+using namespace nfm;
+
+#define QR_COMMON_CHECKS(N)                                   \
+    int rc = check_common(dtype, n_outer, n_inner);           \
+    if (rc) return rc;                                        \
+    if ((N) < 1 || (N) > NFM_MAX_DIM) return NFM_ESIZE;       \
+    const bool nonempty = n_outer > 0 && n_inner > 0;         \
+    (void)nonempty;
+
+extern "C" {
+
+int nfm_qr_givens(int dtype, int64_t n_outer, int64_t n_inner, const nfm_operand *x, const nfm_operand *y, void *out,
+                  void *stream)
+{
+    QR_COMMON_CHECKS(1)
+    if ((rc = check_operand(x, dtype, nonempty))) return rc;
+    if ((rc = check_operand(y, dtype, nonempty))) return rc;
+    if (nonempty && out == nullptr) return NFM_EINVAL;
+    nfm_operand o = packed_out(out, 2, n_inner);
+    QrParams p = mkparams(1, 0, 0, 0, 0, 0.0);
+    return dtype == NFM_F32 ? rec_launch<float, GivensOp<float>>(x, y, nullptr, &o, n_outer, n_inner, p, stream)
+                            : rec_launch<double, GivensOp<double>>(x, y, nullptr, &o, n_outer, n_inner, p, stream);
+}
+
+int nfm_qr_givens_apply(int dtype, int N, int side, int i, int j, int64_t n_outer, int64_t n_inner,
+                        const nfm_operand *a, const nfm_operand *c, const nfm_operand *s, void *stream)
+{
+    QR_COMMON_CHECKS(N)
+    if (side < 0 || side > 2 || i < 0 || j < 0 || i >= N || j >= N) return NFM_EINVAL;
+    if ((rc = check_operand(a, dtype, nonempty))) return rc;
+    if ((rc = check_operand(c, dtype, nonempty))) return rc;
+    if ((rc = check_operand(s, dtype, nonempty))) return rc;
+    if (!nonempty) return NFM_OK;
+    dim3 grid((unsigned)((n_inner + 255) / 256), (unsigned)n_outer, 1);
+    if (dtype == NFM_F32)
+        hipLaunchKernelGGL((givens_apply_kernel<float>), grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           make_opnd(a, 0), make_opnd(c, 0), make_opnd(s, 0), n_inner, N, i, j, side);
+    else
+        hipLaunchKernelGGL((givens_apply_kernel<double>), grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           make_opnd(a, 0), make_opnd(c, 0), make_opnd(s, 0), n_inner, N, i, j, side);
+    return launch_status();
+}
+
+int nfm_qr_householder(int dtype, int N, int basis, int64_t n_outer, int64_t n_inner, const nfm_operand *x,
+                       void *out, void *stream)
+{
+    QR_COMMON_CHECKS(N)
+    if (basis < 0 || basis >= N) return NFM_EINVAL;
+    if ((rc = check_operand(x, dtype, nonempty))) return rc;
+    if (nonempty && out == nullptr) return NFM_EINVAL;
+    QrParams p = mkparams(N, 0, 0, basis, 0, 0.0);
+    return dtype == NFM_F32 ? householder_t<float>(N, n_outer, n_inner, x, out, p, stream)
+                            : householder_t<double>(N, n_outer, n_inner, x, out, p, stream);
+}
+
+int nfm_qr_householder_apply(int dtype, int N, int m, int side, int64_t n_outer, int64_t n_inner,
+                             const nfm_operand *a, const nfm_operand *u, void *stream)
+{
+    QR_COMMON_CHECKS(N)
+    if (side < 0 || side > 2 || m < 1 || m > N) return NFM_EINVAL;
+    if ((rc = check_operand(a, dtype, nonempty))) return rc;
+    if ((rc = check_operand(u, dtype, nonempty))) return rc;
+    if (!nonempty) return NFM_OK;
+    dim3 grid((unsigned)((n_inner + 255) / 256), (unsigned)n_outer, 1);
+    if (dtype == NFM_F32)
+        hipLaunchKernelGGL((householder_apply_kernel<float>), grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           make_opnd(a, 0), make_opnd(u, 0), n_inner, N, m, side);
+    else
+        hipLaunchKernelGGL((householder_apply_kernel<double>), grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           make_opnd(a, 0), make_opnd(u, 0), n_inner, N, m, side);
+    return launch_status();
+}
+
+int nfm_qr_hessenberg(int dtype, int N, int sym, int upper, int with_u, int64_t n_outer, int64_t n_inner,
+                      const nfm_operand *a, void *out, void *stream)
+{
+    QR_COMMON_CHECKS(N)
+    if ((rc = check_operand(a, dtype, nonempty))) return rc;
+    if (nonempty && out == nullptr) return NFM_EINVAL;
+    QrParams p = mkparams(N, upper ? 1 : 0, 0, 0, 0, 0.0);
+    return dtype == NFM_F32 ? hess_t<float>(N, sym, with_u, n_outer, n_inner, a, out, p, stream)
+                            : hess_t<double>(N, sym, with_u, n_outer, n_inner, a, out, p, stream);
+}
+
+int nfm_qr_qr_hessenberg(int dtype, int N, int64_t n_outer, int64_t n_inner, const nfm_operand *h, void *out,
+                         void *stream)
+{
+    QR_COMMON_CHECKS(N)
+    if ((rc = check_operand(h, dtype, nonempty))) return rc;
+    if (nonempty && out == nullptr) return NFM_EINVAL;
+    QrParams p = mkparams(N, 0, 0, 0, 0, 0.0);
+    return dtype == NFM_F32 ? qr_hess_t<float>(N, n_outer, n_inner, h, out, p, stream)
+                            : qr_hess_t<double>(N, n_outer, n_inner, h, out, p, stream);
+}
+
+int nfm_qr_rq_hessenberg(int dtype, int N, int sym, int64_t n_outer, int64_t n_inner, const nfm_operand *h,
+                         const nfm_operand *u, void *out, void *stream)
+{
+    QR_COMMON_CHECKS(N)
+    if ((rc = check_operand(h, dtype, nonempty))) return rc;
+    if (u && (rc = check_operand(u, dtype, nonempty))) return rc;
+    if (nonempty && out == nullptr) return NFM_EINVAL;
+    QrParams p = mkparams(N, 0, sym ? 1 : 0, 0, 0, 0.0);
+    return dtype == NFM_F32 ? rq_hess_t<float>(N, n_outer, n_inner, h, u, out, p, stream)
+                            : rq_hess_t<double>(N, n_outer, n_inner, h, u, out, p, stream);
+}
+
+int nfm_qr_eig_sym(int dtype, int N, int upper, int with_u, int max_iter, double tol, int64_t n_outer,
+                   int64_t n_inner, const nfm_operand *a, void *out, void *stream)
+{
+    QR_COMMON_CHECKS(N)
+    if (max_iter < 0) return NFM_EINVAL;
+    if ((rc = check_operand(a, dtype, nonempty))) return rc;
+    if (nonempty && out == nullptr) return NFM_EINVAL;
+    QrParams p = mkparams(N, upper ? 1 : 0, 1, 0, max_iter, tol);
+    return dtype == NFM_F32 ? eig_sym_t<float>(N, with_u, n_outer, n_inner, a, out, p, stream)
+                            : eig_sym_t<double>(N, with_u, n_outer, n_inner, a, out, p, stream);
+}
+
+} // extern "C"

@@ -1,0 +1,363 @@
+// nfm_qr_core.hpp -- per-lane Givens / Householder / QR-algorithm arithmetic
+// (reference `_impl/qr.py`, real dtypes).
+//
+// Every routine is a template on <T, NT>: NT > 0 is a compile-time order -- all loops
+// unroll, every array index is a constant and the matrices live in VGPRs; NT == 0 is a
+// run-time order n <= 16 with the same source -- the arrays are then indexed at run time
+// and the compiler places them in per-lane scratch memory (orders 9..16: correct, not tuned).
+//
+// Contraction is off and operations follow the CPU restatement's order (which follows the
+// reference's), so results agree with it to the last bit wherever sqrt/div are correctly
+// rounded; the parity tests still allow the north-star tolerance.
+//
+// Deliberate deviations from the reference: Q7 the symmetric mat-vec works
+// for every n (upstream raises for batched n > 5); Q8 `rq_hessenberg` applies its column
+// rotations to rows 0..k+1 (a true R Q) unless the tridiagonal `sym` shortcut is requested;
+// Q9 convergence of the QR iterations is judged PER MATRIX with the reference's criterion
+// (upstream sums it over the whole batch, three host syncs per iteration).
+#pragma once
+#include "nfm_common.hpp"
+#include "nfm_smallmat.hpp"
+
+namespace nfm {
+namespace qr {
+
+template <int NT>
+struct Dim {
+    static constexpr int MAX = NT > 0 ? NT : NFM_MAX_DIM;
+};
+
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double sqrt_(double x) { return __builtin_sqrt(x); }
+template <typename T>
+__device__ __forceinline__ bool finite_(T x)
+{
+    return fabs_(x) < __builtin_huge_val() && x == x;
+}
+
+// _givens_jit :326-334
+template <typename T>
+__device__ __forceinline__ void givens1(T x, T y, T &c, T &s)
+{
+#pragma clang fp contract(off)
+    const T nrm = sqrt_(x * x + y * y);
+    const bool z = nrm == T(0);
+    c = z ? T(1) : x / nrm;
+    s = z ? T(0) : -(y / nrm);
+}
+
+// tmp = s*a0; a0 = a0*c - s*a1; a1 = a1*c + tmp   (_givens_apply_* :370-402)
+template <typename T>
+__device__ __forceinline__ void rot1(T &a0, T &a1, T c, T s)
+{
+#pragma clang fp contract(off)
+    const T tmp = s * a0;
+    a0 = a0 * c - s * a1;
+    a1 = a1 * c + tmp;
+}
+
+// householder_ :55-69 on x[0..m), reflecting onto component `basis` (compile-time or not;
+// the element is picked by a select so that registers are never indexed dynamically)
+template <typename T, int NT>
+__device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis)
+{
+#pragma clang fp contract(off)
+    T xb = T(0);
+#pragma unroll
+    for (int i = 0; i < Dim<NT>::MAX; ++i)
+        if (i < m) xb = (i == basis) ? x[i] : xb;
+    T rho = (xb > T(0)) ? T(1) : ((xb < T(0)) ? T(-1) : T(0));
+    rho = -rho;
+    rho = (rho == T(0)) ? T(1) : rho;
+    T ss = T(0);
+#pragma unroll
+    for (int i = 0; i < Dim<NT>::MAX; ++i)
+        if (i < m) ss += x[i] * x[i];
+    rho *= sqrt_(ss);
+#pragma unroll
+    for (int i = 0; i < Dim<NT>::MAX; ++i)
+        if (i < m) x[i] = (i == basis) ? x[i] - rho : x[i];
+    ss = T(0);
+#pragma unroll
+    for (int i = 0; i < Dim<NT>::MAX; ++i)
+        if (i < m) ss += x[i] * x[i];
+    const T nrm = sqrt_(ss);
+#pragma unroll
+    for (int i = 0; i < Dim<NT>::MAX; ++i)
+        if (i < m) {
+            const T v = x[i] / nrm;
+            x[i] = finite_(v) ? v : T(0);
+        }
+    return rho;
+}
+
+// hessenberg_ :117-141.  up[k][r]: reflector k (length n-1-k), kept when WITH_U.
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n,
+                                            T (&up)[Dim<NT>::MAX][Dim<NT>::MAX])
+{
+#pragma clang fp contract(off)
+    constexpr int MX = Dim<NT>::MAX;
+#pragma unroll
+    for (int k = 0; k < MX - 2; ++k) {
+        if (k < n - 2) {
+            const int m = n - k - 1;
+            T u[MX];
+#pragma unroll
+            for (int r = 0; r < MX; ++r)
+                if (r < m) u[r] = a[k + 1 + r][k];
+            const T alpha = householder1<T, NT>(u, m, 0);
+            if (WITH_U) {
+#pragma unroll
+                for (int r = 0; r < MX; ++r)
+                    if (r < m) up[k][r] = u[r];
+            }
+#pragma unroll
+            for (int c = k + 1; c < MX; ++c)
+                if (c < n) {
+                    T d = T(0);
+#pragma unroll
+                    for (int r = 0; r < MX; ++r)
+                        if (r < m) d += u[r] * a[k + 1 + r][c];
+#pragma unroll
+                    for (int r = 0; r < MX; ++r)
+                        if (r < m) a[k + 1 + r][c] -= T(2) * (u[r] * d);
+                }
+#pragma unroll
+            for (int r = 0; r < MX; ++r)
+                if (r < n) {
+                    T d = T(0);
+#pragma unroll
+                    for (int c = 0; c < MX; ++c)
+                        if (c < m) d += a[r][k + 1 + c] * u[c];
+#pragma unroll
+                    for (int c = 0; c < MX; ++c)
+                        if (c < m) a[r][k + 1 + c] -= T(2) * (d * u[c]);
+                }
+            a[k + 1][k] = alpha;
+#pragma unroll
+            for (int r = k + 2; r < MX; ++r)
+                if (r < n) a[r][k] = T(0);
+        }
+    }
+}
+
+// hessenberg_sym_lower_ :296-323 on a matrix whose LOWER triangle holds the data (the
+// caller mirrors the requested triangle on load, which is what the reference's transposed
+// view does for upper=True).  Output: symmetric tridiagonal, both halves filled.
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n,
+                                                T (&up)[Dim<NT>::MAX][Dim<NT>::MAX])
+{
+#pragma clang fp contract(off)
+    constexpr int MX = Dim<NT>::MAX;
+#pragma unroll
+    for (int k = 0; k < MX - 2; ++k) {
+        if (k < n - 2) {
+            const int m = n - k - 1, o = k + 1;
+            T u[MX], v[MX];
+#pragma unroll
+            for (int r = 0; r < MX; ++r)
+                if (r < m) u[r] = a[o + r][k];
+            const T alpha = householder1<T, NT>(u, m, 0);
+            if (WITH_U) {
+#pragma unroll
+                for (int r = 0; r < MX; ++r)
+                    if (r < m) up[k][r] = u[r];
+            }
+#pragma unroll
+            for (int i = 0; i < MX; ++i)
+                if (i < m) {
+                    T y = T(0);
+#pragma unroll
+                    for (int j = 0; j < MX; ++j)
+                        if (j < m) y += (i >= j ? a[o + i][o + j] : a[o + j][o + i]) * u[j];
+                    v[i] = y;
+                }
+            T d = T(0);
+#pragma unroll
+            for (int i = 0; i < MX; ++i)
+                if (i < m) d += u[i] * v[i];
+#pragma unroll
+            for (int i = 0; i < MX; ++i)
+                if (i < m) v[i] = (v[i] - u[i] * d) * T(2);
+#pragma unroll
+            for (int i = 0; i < MX; ++i)
+                if (i < m) {
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        const T w = (i == j) ? (u[i] * v[i]) * T(2) : (u[j] * v[i] + v[j] * u[i]);
+                        a[o + i][o + j] -= w;
+                    }
+                }
+            a[o][k] = alpha;
+#pragma unroll
+            for (int r = k + 2; r < MX; ++r)
+                if (r < n) a[r][k] = T(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MX; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+            if (i < n) a[j][i] = a[i][j];
+}
+
+// qr_hessenberg_ :432-454
+template <typename T, int NT>
+__device__ __forceinline__ void qr_hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                               T (&q)[Dim<NT>::MAX][Dim<NT>::MAX], int n)
+{
+    constexpr int MX = Dim<NT>::MAX;
+#pragma unroll
+    for (int i = 0; i < MX; ++i)
+#pragma unroll
+        for (int j = 0; j < MX; ++j) q[i][j] = (i == j) ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < MX - 1; ++k) {
+        if (k < n - 1) {
+            T c, s;
+            givens1(a[k][k], a[k + 1][k], c, s);
+#pragma unroll
+            for (int j = k; j < MX; ++j)
+                if (j < n) rot1(a[k][j], a[k + 1][j], c, s);
+#pragma unroll
+            for (int i = 0; i < k + 2; ++i) rot1(q[i][k], q[i][k + 1], c, s);
+        }
+    }
+}
+
+// One R Q step on the leading m x m block; WITH_U also rotates the columns of u (n rows).
+// sym: the tridiagonal shortcut of _rq_hessenberg_jit_ :457-485; otherwise the full ranges.
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void rq_step1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                         T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m, bool sym)
+{
+    constexpr int MX = Dim<NT>::MAX;
+    T lc[MX], ls[MX];
+#pragma unroll
+    for (int k = 0; k < MX - 1; ++k) {
+        if (k < m - 1) {
+            givens1(a[k][k], a[k + 1][k], lc[k], ls[k]);
+#pragma unroll
+            for (int j = k; j < MX; ++j)
+                if (j < m && (!sym || j < k + 3)) rot1(a[k][j], a[k + 1][j], lc[k], ls[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MX - 1; ++k) {
+        if (k < m - 1) {
+#pragma unroll
+            for (int i = 0; i < k + 2; ++i)
+                if (!sym || i >= k - 1) rot1(a[i][k], a[i][k + 1], lc[k], ls[k]);
+            if (WITH_U) {
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < n) rot1(u[i][k], u[i][k + 1], lc[k], ls[k]);
+            }
+        }
+    }
+}
+
+// _wilkinson :558-569 on the trailing 2x2 of the active m x m block
+template <typename T>
+__device__ __forceinline__ T wilkinson1(T h0, T h1, T b)
+{
+#pragma clang fp contract(off)
+    const T b2 = b * b;
+    T d = (h0 - h1) / T(2);
+    const T s = (d < T(0)) ? T(-1) : T(1);
+    d = fabs_(d) + sqrt_(d * d + b2);
+    d = (d == T(0)) ? T(1) : d;
+    return h1 - s * b2 / d;
+}
+
+// _qr_explicit(_vectors)_jit_ :572-656 with sym = True; convergence per lane (Q9)
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                             T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int max_iter, double tol)
+{
+#pragma clang fp contract(off)
+    constexpr int MX = Dim<NT>::MAX;
+    if (WITH_U) {
+#pragma unroll
+        for (int i = 0; i < MX; ++i)
+#pragma unroll
+            for (int j = 0; j < MX; ++j) u[i][j] = (i == j) ? T(1) : T(0);
+    }
+#pragma unroll
+    for (int m = MX; m >= 2; --m) {
+        if (m <= n) {
+            double sos_prev = 0.0;
+            for (int it = 0; it < max_iter; ++it) {
+                const T sigma = wilkinson1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
+#pragma unroll
+                for (int i = 0; i < m; ++i) h[i][i] -= sigma;
+                rq_step1<T, NT, WITH_U>(h, u, n, m, true);
+#pragma unroll
+                for (int i = 0; i < m; ++i) h[i][i] += sigma;
+                const T bb = fabs_(h[m - 1][m - 2]), a0 = fabs_(h[m - 1][m - 1]), a1 = fabs_(h[m - 2][m - 2]);
+                const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
+                if ((double)sos_lower < tol * (double)sos_diag) {
+#pragma unroll
+                    for (int j = 0; j < m - 1; ++j) h[m - 1][j] = T(0);
+                    break;
+                }
+                if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
+                    const double sos_new = (double)(sos_lower / sos_diag);
+                    const double rel = (sos_prev - sos_new) / sos_prev;
+                    if (sos_prev != 0.0 && (rel < 0 ? -rel : rel) < tol * 1e-3) break;
+                    sos_prev = sos_new;
+                }
+            }
+        }
+    }
+}
+
+// apply P = I - 2 w w^T (w of length m, acting on the trailing m rows) from the left
+// householder_apply_ :72-106, side='left'
+template <typename T, int NT>
+__device__ __forceinline__ void reflect_left1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m,
+                                              const T (&w)[Dim<NT>::MAX])
+{
+#pragma clang fp contract(off)
+    constexpr int MX = Dim<NT>::MAX;
+    const int k0 = n - m;
+#pragma unroll
+    for (int c = 0; c < MX; ++c)
+        if (c < n) {
+            T d = T(0);
+#pragma unroll
+            for (int r = 0; r < MX; ++r)
+                if (r >= k0 && r < n) d += w[r - k0 < 0 ? 0 : r - k0] * a[r][c];
+#pragma unroll
+            for (int r = 0; r < MX; ++r)
+                if (r >= k0 && r < n) a[r][c] -= T(2) * (w[r - k0 < 0 ? 0 : r - k0] * d);
+        }
+}
+
+// _fwd_eig_sym :665-681.  `a` holds the symmetric input (the requested triangle already
+// mirrored); on return vals = diagonal, and for WITH_U the columns of u are the eigenvectors.
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void eig_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                         int n, int max_iter, double tol)
+{
+    constexpr int MX = Dim<NT>::MAX;
+    T up[MX][MX];
+    hessenberg_sym1<T, NT, WITH_U>(a, n, up);
+    qr_explicit1<T, NT, WITH_U>(a, u, n, max_iter, tol);
+    if (WITH_U) {
+        // householder_apply_(u, q, side='left', inverse=True): reflectors in reverse order
+#pragma unroll
+        for (int k = MX - 3; k >= 0; --k)
+            if (k < n - 2) {
+                T w[MX];
+#pragma unroll
+                for (int r = 0; r < MX; ++r) w[r] = up[k][r];
+                reflect_left1<T, NT>(u, n, n - k - 1, w);
+            }
+    }
+}
+
+} // namespace qr
+} // namespace nfm

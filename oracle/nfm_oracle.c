@@ -16,6 +16,8 @@
  *   _impl/batched.py:21-190 batchdet / batchinv / batchmatvec (CPU = torch LU
  *                          fallbacks; TorchScript adjugate forms behind `closed`)
  *   reduce.py:255-510      nansum / nanmax / nanmin / sum / max / min
+ *   _impl/qr.py:55-681     givens, givens_apply, householder(_apply), hessenberg(_sym),
+ *                          qr_hessenberg, rq_hessenberg, eig_sym (nfm_oracle_qr.inc)
  *
  * Pinning: checked against golden vectors produced by the real reference in
  * the build container (tests/golden/make_golden.py -> tests/golden/ npz files);
@@ -34,21 +36,29 @@
 #define T float
 #define SUF f32
 #define FABS fabsf
+#define SQRT sqrtf
+#define ISFINITE(x) isfinite(x)
 #define ADDCMUL(self, a, b) fmaf((a), (b), (self))
 #include "nfm_oracle_body.inc"
 #undef T
 #undef SUF
 #undef FABS
+#undef SQRT
+#undef ISFINITE
 #undef ADDCMUL
 
 #define T double
 #define SUF f64
 #define FABS fabs
+#define SQRT sqrt
+#define ISFINITE(x) isfinite(x)
 #define ADDCMUL(self, a, b) fma((a), (b), (self))
 #include "nfm_oracle_body.inc"
 #undef T
 #undef SUF
 #undef FABS
+#undef SQRT
+#undef ISFINITE
 #undef ADDCMUL
 
 #define BAD_DTYPE (-2)
@@ -146,6 +156,70 @@ int nfm_oracle_reduce(int dtype, int op, int64_t outer, int64_t red, int64_t inn
     if (dtype == 0) return nfm_oracle_reduce_f32(op, outer, red, inner, x, out, out_f64);
     if (dtype == 1) return nfm_oracle_reduce_f64(op, outer, red, inner, x, out, out_f64);
     return BAD_DTYPE;
+}
+
+#define DISPATCH(call32, call64) do { if (dtype == 0) return call32; if (dtype == 1) return call64; return BAD_DTYPE; } while (0)
+
+int nfm_oracle_qr_givens(int dtype, int64_t n, const void *x, const void *y, void *c, void *s)
+{
+    DISPATCH(nfm_oracle_qr_givens_f32(n, x, y, c, s), nfm_oracle_qr_givens_f64(n, x, y, c, s));
+}
+
+int nfm_oracle_qr_givens_apply(int dtype, int N, int64_t n, int side, int i, int j, void *a, const void *c,
+                               const void *s)
+{
+    CHECK_M(N);
+    if (i < 0 || j < 0 || i >= N || j >= N) return BAD_SIZE;
+    DISPATCH(nfm_oracle_qr_givens_apply_f32(N, n, side, i, j, a, c, s),
+             nfm_oracle_qr_givens_apply_f64(N, n, side, i, j, a, c, s));
+}
+
+int nfm_oracle_qr_householder(int dtype, int N, int64_t n, int basis, void *x, void *alpha)
+{
+    CHECK_M(N);
+    DISPATCH(nfm_oracle_qr_householder_f32(N, n, basis, x, alpha), nfm_oracle_qr_householder_f64(N, n, basis, x, alpha));
+}
+
+int nfm_oracle_qr_householder_apply(int dtype, int N, int m, int64_t n, int side, void *a, const void *u)
+{
+    CHECK_M(N);
+    if (m < 1 || m > N) return BAD_SIZE;
+    DISPATCH(nfm_oracle_qr_householder_apply_f32(N, m, n, side, a, u),
+             nfm_oracle_qr_householder_apply_f64(N, m, n, side, a, u));
+}
+
+int nfm_oracle_qr_hessenberg(int dtype, int N, int64_t n, void *a, void *upack)
+{
+    CHECK_M(N);
+    DISPATCH(nfm_oracle_qr_hessenberg_f32(N, n, a, upack), nfm_oracle_qr_hessenberg_f64(N, n, a, upack));
+}
+
+int nfm_oracle_qr_hessenberg_sym(int dtype, int N, int64_t n, int upper, int fill, void *a, void *upack)
+{
+    CHECK_M(N);
+    DISPATCH(nfm_oracle_qr_hessenberg_sym_f32(N, n, upper, fill, a, upack),
+             nfm_oracle_qr_hessenberg_sym_f64(N, n, upper, fill, a, upack));
+}
+
+int nfm_oracle_qr_qr_hessenberg(int dtype, int N, int64_t n, void *a, void *q)
+{
+    CHECK_M(N);
+    DISPATCH(nfm_oracle_qr_qr_hessenberg_f32(N, n, a, q), nfm_oracle_qr_qr_hessenberg_f64(N, n, a, q));
+}
+
+int nfm_oracle_qr_rq_hessenberg(int dtype, int N, int64_t n, int sym, int true_rq, void *a, void *u)
+{
+    CHECK_M(N);
+    DISPATCH(nfm_oracle_qr_rq_hessenberg_f32(N, n, sym, true_rq, a, u),
+             nfm_oracle_qr_rq_hessenberg_f64(N, n, sym, true_rq, a, u));
+}
+
+int nfm_oracle_qr_eig_sym(int dtype, int N, int64_t n, int upper, int compute_u, int max_iter, double tol, void *a,
+                          void *vals, void *vecs)
+{
+    CHECK_M(N);
+    DISPATCH(nfm_oracle_qr_eig_sym_f32(N, n, upper, compute_u, max_iter, tol, a, vals, vecs),
+             nfm_oracle_qr_eig_sym_f64(N, n, upper, compute_u, max_iter, tol, a, vals, vecs));
 }
 
 int nfm_oracle_version(void) { return 1; }

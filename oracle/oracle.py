@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 __all__ = ['build', 'lib', 'sym_solve', 'sym_matvec', 'sym_invert', 'sym_det', 'sym_to_full',
-           'sym_outer', 'sym_matmul', 'batch_inv', 'batch_det', 'batch_matvec', 'reduce',
+           'sym_outer', 'sym_matmul', 'batch_inv', 'batch_det', 'batch_matvec', 'reduce', 'givens', 'givens_apply', 'householder',
+           'householder_apply', 'hessenberg', 'hessenberg_sym', 'qr_hessenberg', 'rq_hessenberg', 'eig_sym',
            'set_num_threads']
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,7 +21,7 @@ _lib = None
 
 def build(force=False):
     """Compile the C restatement with gcc (seconds)."""
-    src = [os.path.join(_HERE, f) for f in ('nfm_oracle.c', 'nfm_oracle_body.inc')]
+    src = [os.path.join(_HERE, f) for f in ('nfm_oracle.c', 'nfm_oracle_body.inc', 'nfm_oracle_qr.inc')]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
         return _SO
@@ -218,3 +219,96 @@ def reduce(op, x, dim=None, keepdim=False, out_f64=False):
     if keepdim:
         out = out.reshape([1 if d in dims else x.shape[d] for d in range(nd)])
     return out
+
+
+# ------------------------------------------------------------------ QR family
+_SIDE = {'left': 0, 'right': 1, 'both': 2}
+
+
+def _nb(a, nd):
+    return int(np.prod(a.shape[:a.ndim - nd], dtype=np.int64))
+
+
+def givens(x, y):
+    x, y = np.broadcast_arrays(_c(x), _c(y))
+    x, y = _c(x), _c(y, x.dtype)
+    c, s = np.empty_like(x), np.empty_like(x)
+    _chk(lib().nfm_oracle_qr_givens(_dt(x), ctypes.c_int64(x.size), _p(x), _p(y), _p(c), _p(s)))
+    return c, s
+
+
+def givens_apply(a, c, s, i=0, j=None, side='both'):
+    a = np.array(a, copy=True, order='C')
+    N = a.shape[-1]
+    j = i + 1 if j is None else j
+    shp = a.shape[:-2] + (N,)
+    c = _c(np.broadcast_to(np.asarray(c, a.dtype), shp))
+    s = _c(np.broadcast_to(np.asarray(s, a.dtype), shp))
+    _chk(lib().nfm_oracle_qr_givens_apply(_dt(a), N, ctypes.c_int64(_nb(a, 2)), _SIDE[side], i, j, _p(a), _p(c), _p(s)))
+    return a
+
+
+def householder(x, basis=0):
+    x = np.array(x, copy=True, order='C')
+    alpha = np.empty(x.shape[:-1], x.dtype)
+    _chk(lib().nfm_oracle_qr_householder(_dt(x), x.shape[-1], ctypes.c_int64(_nb(x, 1)), basis, _p(x), _p(alpha)))
+    return x, alpha
+
+
+def householder_apply(a, u, side='both', inverse=False):
+    a = np.array(a, copy=True, order='C')
+    us = list(u) if isinstance(u, (list, tuple)) else [u]
+    if inverse:
+        us = us[::-1]
+    N = a.shape[-1]
+    for uk in us:
+        uk = _c(np.broadcast_to(np.asarray(uk, a.dtype), a.shape[:-2] + (uk.shape[-1],)))
+        _chk(lib().nfm_oracle_qr_householder_apply(_dt(a), N, uk.shape[-1], ctypes.c_int64(_nb(a, 2)),
+                                                   _SIDE[side], _p(a), _p(uk)))
+    return a
+
+
+def _unpack_u(upack, N):
+    return [upack[..., k, :N - 1 - k].copy() for k in range(max(N - 2, 0))]
+
+
+def hessenberg(a, compute_u=False):
+    a = np.array(a, copy=True, order='C')
+    N = a.shape[-1]
+    up = np.zeros(a.shape[:-2] + (max(N - 2, 0), N - 1), a.dtype) if compute_u else None
+    _chk(lib().nfm_oracle_qr_hessenberg(_dt(a), N, ctypes.c_int64(_nb(a, 2)), _p(a), _p(up)))
+    return (a, _unpack_u(up, N)) if compute_u else a
+
+
+def hessenberg_sym(a, upper=True, fill=True, compute_u=False):
+    a = np.array(a, copy=True, order='C')
+    N = a.shape[-1]
+    up = np.zeros(a.shape[:-2] + (max(N - 2, 0), N - 1), a.dtype) if compute_u else None
+    _chk(lib().nfm_oracle_qr_hessenberg_sym(_dt(a), N, ctypes.c_int64(_nb(a, 2)), int(upper), int(fill), _p(a), _p(up)))
+    return (a, _unpack_u(up, N)) if compute_u else a
+
+
+def qr_hessenberg(h):
+    r = np.array(h, copy=True, order='C')
+    q = np.empty_like(r)
+    _chk(lib().nfm_oracle_qr_qr_hessenberg(_dt(r), r.shape[-1], ctypes.c_int64(_nb(r, 2)), _p(r), _p(q)))
+    return q, r
+
+
+def rq_hessenberg(h, u=None, sym=False, true_rq=True):
+    h = np.array(h, copy=True, order='C')
+    if u is not None:
+        u = np.array(u, dtype=h.dtype, copy=True, order='C')
+    _chk(lib().nfm_oracle_qr_rq_hessenberg(_dt(h), h.shape[-1], ctypes.c_int64(_nb(h, 2)), int(sym), int(true_rq),
+                                           _p(h), _p(u)))
+    return h if u is None else (h, u)
+
+
+def eig_sym(a, compute_u=False, upper=True, max_iter=1024, tol=1e-32):
+    a = np.array(a, copy=True, order='C')
+    N = a.shape[-1]
+    vals = np.empty(a.shape[:-1], a.dtype)
+    vecs = np.empty_like(a) if compute_u else None
+    _chk(lib().nfm_oracle_qr_eig_sym(_dt(a), N, ctypes.c_int64(_nb(a, 2)), int(upper), int(compute_u), int(max_iter),
+                                     ctypes.c_double(tol), _p(a), _p(vals), _p(vecs)))
+    return (vals, vecs) if compute_u else vals

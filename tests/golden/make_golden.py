@@ -210,7 +210,8 @@ def gen_qr(ref):
         nb = 16
         x = torch.randn(nb, dtype=torch.float64, generator=gen).to(dtype)
         y = torch.randn(nb, dtype=torch.float64, generator=gen).to(dtype)
-        x[0] = 0; y[0] = 0
+        x[0] = 0
+        y[0] = 0
         x[1] = 0
         y[2] = 0
         c, s = Q.givens(x, y)
@@ -218,58 +219,78 @@ def gen_qr(ref):
         out[f'{dname}_givens_y'] = npy(y)
         out[f'{dname}_givens_c'] = npy(c)
         out[f'{dname}_givens_s'] = npy(s)
-        for n_ in (1, 2, 3, 4, 5, 6, 8):
+        for n_ in (1, 2, 3, 4, 5, 6, 8, 12):
             k = f'{dname}_n{n_}_'
             a = torch.randn(nb, n_, n_, dtype=torch.float64, generator=gen).to(dtype)
             out[k + 'a'] = npy(a)
-            # householder
+            # householder (+ projection alpha) on every basis worth testing
             v = torch.randn(nb, n_, dtype=torch.float64, generator=gen).to(dtype)
-            v[0] = 0
+            v[0] = 0            # zero vector: reflector must come out as zeros, not NaN
+            if n_ > 1:
+                v[1, 0] = 0     # zero pivot component: sign(0) -> +1
             out[k + 'hh_x'] = npy(v)
             for basis in sorted({0, n_ - 1}):
-                u, rho = Q.householder(v, basis=basis)
+                u, alpha = Q.householder(v, basis=basis, return_alpha=True)
                 out[k + f'hh_u_b{basis}'] = npy(u)
-                out[k + f'hh_rho_b{basis}'] = npy(rho)
-            u, _ = Q.householder(v)
+                out[k + f'hh_alpha_b{basis}'] = npy(alpha)
+            u = Q.householder(v)
             for side in ('left', 'right', 'both'):
                 out[k + f'hh_apply_{side}'] = npy(Q.householder_apply(a, u, side=side))
+            if n_ >= 3:     # a shorter reflector acts on the trailing block only
+                u2 = Q.householder(v[:, 1:])
+                out[k + 'hh_apply_short'] = npy(Q.householder_apply(a, u2, side='both'))
+                out[k + 'hh_apply_two_inv'] = npy(Q.householder_apply(a, [u, u2], side='left', inverse=True))
             # givens_apply
             if n_ >= 2:
                 cc, ss = Q.givens(a[:, 0, 0], a[:, 1, 0])
-                for side in ('left', 'right', 'both'):
-                    out[k + f'givens_apply_{side}'] = npy(
-                        Q.givens_apply(a, cc, ss, 0, n_ - 1, side=side))
                 out[k + 'ga_c'] = npy(cc)
                 out[k + 'ga_s'] = npy(ss)
+                for side in ('left', 'right', 'both'):
+                    out[k + f'givens_apply_{side}'] = npy(Q.givens_apply(a, cc[:, None], ss[:, None], 0, n_ - 1, side=side))
+                out[k + 'givens_apply_default_j'] = npy(Q.givens_apply(a, cc[:, None], ss[:, None], 0, side='left'))
             # hessenberg (general) and QR of a Hessenberg matrix
             h, us = Q.hessenberg(a, compute_u=True)
             out[k + 'hess'] = npy(h)
             for i, ui in enumerate(us):
                 out[k + f'hess_u{i}'] = npy(ui)
-            out[k + 'hess_nu'] = np.asarray(len(us))
             hz = torch.triu(a, -1)
             out[k + 'hz'] = npy(hz)
             qq, rr = Q.qr_hessenberg(hz)
             out[k + 'qrh_q'] = npy(qq)
             out[k + 'qrh_r'] = npy(rr)
-            # symmetric: tridiagonalisation + eigenvalues (reference works for n <= 5)
+            # the reference's rq_hessenberg is only right for n <= 3 or tridiagonal input
+            # (quirk Q8); golden for the general case = r @ q of its own (correct) QR
+            out[k + 'rq_true'] = npy(rr @ qq)
+            if n_ <= 3:
+                out[k + 'rq_ref'] = npy(Q.rq_hessenberg(hz))
+            # symmetric: tridiagonalisation + eigenvalues (reference works for n <= 5, quirk Q7)
             sym = (a + a.transpose(-1, -2)) / 2
             out[k + 'sym'] = npy(sym)
+            out[k + 'eigvalsh'] = npy(torch.linalg.eigvalsh(sym.double()))
             if n_ <= 5:
                 for upper in (True, False):
                     t, us = Q.hessenberg_sym(sym, upper=upper, fill=True, compute_u=True)
                     out[k + f'hess_sym_{int(upper)}'] = npy(t)
-                ev = Q.eig_sym(sym)
-                out[k + 'eig'] = npy(ev)
-                ev2, evec = Q.eig_sym(sym, compute_u=True)
-                out[k + 'eig_u_val'] = npy(ev2)
-                out[k + 'eig_u_vec'] = npy(evec)
-                # RQ step on the symmetric tridiagonal matrix (the only use the
-                # reference's rq_hessenberg is valid for, quirk Q8)
-                t3, _ = Q.hessenberg_sym(sym, upper=True, fill=True)
+                    for i, ui in enumerate(us):
+                        out[k + f'hess_sym_{int(upper)}_u{i}'] = npy(ui)
+                    # un-symmetrised input: only one triangle may be read
+                    t2 = Q.hessenberg_sym(a, upper=upper, fill=True)
+                    out[k + f'hess_nonsym_{int(upper)}'] = npy(t2)
+                    # The reference judges convergence on batch-wide sums (quirk Q9), so the
+                    # ORDER of its (unsorted) eigenvalues depends on what else is in the batch.
+                    # Per-matrix goldens = the reference called on one matrix at a time.
+                    out[k + f'eig_{int(upper)}'] = npy(torch.cat([Q.eig_sym(a[i:i + 1], upper=upper) for i in range(nb)]))
+                out[k + 'eig'] = npy(torch.cat([Q.eig_sym(sym[i:i + 1]) for i in range(nb)]))
+                out[k + 'eig_batched'] = npy(Q.eig_sym(sym))
+                pairs = [Q.eig_sym(sym[i:i + 1], compute_u=True) for i in range(nb)]
+                out[k + 'eig_u_val'] = npy(torch.cat([p[0] for p in pairs]))
+                out[k + 'eig_u_vec'] = npy(torch.cat([p[1] for p in pairs]))
+                t3 = Q.hessenberg_sym(sym, upper=True, fill=True)
                 out[k + 'tri'] = npy(t3)
-                out[k + 'rq_tri'] = npy(Q.rq_hessenberg(t3)[0] if isinstance(Q.rq_hessenberg(t3), tuple) else Q.rq_hessenberg(t3))
-            out[k + 'eigvalsh'] = npy(torch.linalg.eigvalsh(sym))
+                out[k + 'rq_tri'] = npy(Q.rq_hessenberg(t3))
+                uu = torch.eye(n_, dtype=dtype).expand(nb, n_, n_).clone()
+                r_h, r_u = Q.rq_hessenberg(t3, uu)
+                out[k + 'rq_tri_u'] = npy(r_u)
     np.savez_compressed(os.path.join(HERE, 'qr.npz'), **out)
     return len(out)
 
@@ -277,7 +298,7 @@ def gen_qr(ref):
 if __name__ == '__main__':
     torch.set_num_threads(1)
     ref = load_ref()
-    which = sys.argv[1:] or ['sym', 'batched', 'reduce']
+    which = sys.argv[1:] or ['sym', 'batched', 'reduce', 'qr']
     for w in which:
         n = globals()['gen_' + w](ref)
         print(w, n, 'arrays')

@@ -126,3 +126,88 @@ def test_reduce_dims(oracle, golden_reduce, dn):
 
 def test_reduce_empty(oracle, golden_reduce):
     assert oracle.reduce('nansum', np.zeros(0, np.float32)) == golden_reduce['f32_empty_nansum'] == 0
+
+
+# ------------------------------------------------------------------ QR family
+# The reference's own fp32 results drift from the fp64 truth as the order grows (its
+# Householder reductions are ~9e-6 off at n = 12); the tolerance scales accordingly.
+def qr_tol(dn, n):
+    return TOL[dn] * max(1.0, n * n / 4.0)
+
+
+QR_NS = (1, 2, 3, 4, 5, 6, 8, 12)
+
+
+@pytest.fixture(scope='session')
+def golden_qr():
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, 'qr.npz'))
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_qr_givens(oracle, golden_qr, dn):
+    g = golden_qr
+    c, s = oracle.givens(g[dn + '_givens_x'], g[dn + '_givens_y'])
+    assert relerr(c, g[dn + '_givens_c']) <= TOL[dn] and relerr(s, g[dn + '_givens_s']) <= TOL[dn]
+    assert c[0] == 1 and s[0] == 0          # x = y = 0 -> identity rotation
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('n', QR_NS)
+def test_qr_family(oracle, golden_qr, dn, n):
+    g, k, tol = golden_qr, f'{dn}_n{n}_', qr_tol(dn, n)
+    a, v = g[k + 'a'], g[k + 'hh_x']
+    for b in sorted({0, n - 1}):
+        u, al = oracle.householder(v, b)
+        assert relerr(u, g[k + f'hh_u_b{b}']) <= tol and relerr(al, g[k + f'hh_alpha_b{b}']) <= tol
+        assert not np.isnan(u).any()
+    u, _ = oracle.householder(v)
+    for side in ('left', 'right', 'both'):
+        assert relerr(oracle.householder_apply(a, u, side), g[k + f'hh_apply_{side}']) <= tol
+    if n >= 3:
+        u2, _ = oracle.householder(v[:, 1:])
+        assert relerr(oracle.householder_apply(a, u2, 'both'), g[k + 'hh_apply_short']) <= tol
+        assert relerr(oracle.householder_apply(a, [u, u2], 'left', True), g[k + 'hh_apply_two_inv']) <= tol
+    if n >= 2:
+        cc, ss = g[k + 'ga_c'][:, None], g[k + 'ga_s'][:, None]
+        for side in ('left', 'right', 'both'):
+            assert relerr(oracle.givens_apply(a, cc, ss, 0, n - 1, side), g[k + f'givens_apply_{side}']) <= tol
+        assert relerr(oracle.givens_apply(a, cc, ss, 0, None, 'left'), g[k + 'givens_apply_default_j']) <= tol
+    h, us = oracle.hessenberg(a, True)
+    assert relerr(h, g[k + 'hess']) <= tol
+    for i, ui in enumerate(us):
+        assert relerr(ui, g[k + f'hess_u{i}']) <= tol
+    q, r = oracle.qr_hessenberg(g[k + 'hz'])
+    assert relerr(q, g[k + 'qrh_q']) <= tol and relerr(r, g[k + 'qrh_r']) <= tol
+    assert relerr(oracle.rq_hessenberg(g[k + 'hz']), g[k + 'rq_true']) <= tol
+    if n <= 3:
+        assert relerr(oracle.rq_hessenberg(g[k + 'hz'], true_rq=False), g[k + 'rq_ref']) <= tol
+    # eigenvalues of the symmetrised matrix against LAPACK (sorted), any n
+    ev = np.sort(oracle.eig_sym(g[k + 'sym']), -1)
+    assert relerr(ev, g[k + 'eigvalsh']) <= 4 * tol
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5])
+def test_qr_sym_family(oracle, golden_qr, dn, n):
+    """orders where the reference itself runs (quirk Q7)"""
+    g, k, tol = golden_qr, f'{dn}_n{n}_', qr_tol(dn, n)
+    a, sym = g[k + 'a'], g[k + 'sym']
+    for up in (1, 0):
+        t, us = oracle.hessenberg_sym(sym, bool(up), True, True)
+        assert relerr(t, g[k + f'hess_sym_{up}']) <= tol
+        for i, ui in enumerate(us):
+            assert relerr(ui, g[k + f'hess_sym_{up}_u{i}']) <= tol
+        # un-symmetrised input: only the requested triangle may be read
+        assert relerr(oracle.hessenberg_sym(a, bool(up), True), g[k + f'hess_nonsym_{up}']) <= tol
+        assert relerr(oracle.eig_sym(a, upper=bool(up)), g[k + f'eig_{up}']) <= 4 * tol
+    # same ORDER (deflation order) and same eigenvector signs as the reference on one matrix
+    assert relerr(oracle.eig_sym(sym), g[k + 'eig']) <= 4 * tol
+    ev, evec = oracle.eig_sym(sym, True)
+    assert relerr(ev, g[k + 'eig_u_val']) <= 4 * tol and relerr(evec, g[k + 'eig_u_vec']) <= 8 * tol
+    # batched upstream call: same multiset (its order depends on the batch, quirk Q9)
+    assert relerr(np.sort(ev, -1), np.sort(g[k + 'eig_batched'], -1)) <= 4 * tol
+    assert relerr(oracle.rq_hessenberg(g[k + 'tri']), g[k + 'rq_tri']) <= tol
+    eye = np.broadcast_to(np.eye(n, dtype=a.dtype), a.shape)
+    assert relerr(oracle.rq_hessenberg(g[k + 'tri'], eye)[1], g[k + 'rq_tri_u']) <= tol
