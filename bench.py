@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s ach
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
-    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--steps', type=int, default=100)
+    p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--workload', default='sym_solve4')
     p.add_argument('--n', type=float, default=None, help='batch per GPU (default: the config size)')
     p.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
@@ -168,6 +168,31 @@ def make_workload(name, n_arg, device, rank, layout):
     return w
 
 
+def host_cores():
+    """CPU threads this process may actually use: the affinity mask, capped by the cgroup
+    CPU quota when there is one (a GPU box gives each GPU a share of the host)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    cores = min(cores, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    cores = min(cores, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return cores
+
+
 def time_cpu(fn, units, budget_s):
     """best-of repeated runs of the oracle within ~budget_s seconds"""
     fn()
@@ -249,15 +274,18 @@ def main():
     if world == 1 and not a.no_cpu:
         import oracle as O
         O.build()
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
-        O.set_num_threads(cores)
-        rate, sample = w.cpu(12.0)
-        line['cpu_baseline'] = {'value': rate, 'unit': w.unit, 'cores': cores, 'kind': 'port',
-                                'sample': sample + ' (C/OpenMP oracle, best of repeated runs, ~12 s)'}
+        avail = host_cores()
+        best = None
+        # a one-GPU box owns a share of the host (16 threads by the pool's rule); try that
+        # and everything visible, keep the faster, report the thread count actually used
+        for cores in sorted({min(16, avail), avail}):
+            O.set_num_threads(cores)
+            rate, sample = w.cpu(6.0)
+            if best is None or rate > best[0]:
+                best = (rate, cores, sample)
+        line['cpu_baseline'] = {'value': best[0], 'unit': w.unit, 'cores': best[1], 'kind': 'port',
+                                'sample': best[2] + ' (C/OpenMP oracle, best of repeated runs, ~6 s per thread count)',
+                                'host_threads_visible': avail}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

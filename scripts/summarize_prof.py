@@ -37,6 +37,14 @@ def main():
         for k, r in seen.items():
             lines.append(f"| `{k}` | {r['VGPR_Count']} | {r['SGPR_Count']} | {r['LDS_Block_Size']} | {r['Scratch_Size']} | "
                          f"{r['Workgroup_Size_X']} | {r['Grid_Size_X']}x{r['Grid_Size_Y']} |")
+        durs = {}
+        for r in rows:
+            durs.setdefault(trim(r['Kernel_Name']), []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        lines += ['', 'durations of the nfm kernels in dispatch order, ns (the first launches are warm-up: cold TLB / '
+                  'first touch; bench.py times the launches after its warm-up):', '']
+        for k, v in durs.items():
+            vs = sorted(v)
+            lines.append(f"* `{k}`: {v[:24]}{' ...' if len(v) > 24 else ''} -- median {vs[len(vs) // 2]}, min {vs[0]}")
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:14]))
 
