@@ -209,6 +209,105 @@ struct TileIO {
     }
 };
 
+// ---------------------------------------------------------------------------
+// SoaIO<T, R, Cc, TILE>: component-major ("SoA", channel-first) operands -- element i of
+// component (r, c) at ptr[i + r*sr + c*sc].  Consecutive lanes already touch consecutive
+// addresses, but one element per lane is only a 4-byte access; instead the workgroup
+// streams every component's TILE-element run with 16-byte vectors (1 KiB per wave
+// instruction) into an LDS image laid out [component][TILE], from which lane t reads
+// element t of every component (stride-1 across lanes: conflict-free).
+// ---------------------------------------------------------------------------
+template <typename T, int R, int Cc, int TILE>
+struct SoaIO {
+    using V = typename VecOf<T>::type;
+    static constexpr int kVec = VecOf<T>::N;
+    static constexpr int C = R * Cc;
+    static constexpr int kVecPerComp = TILE / kVec;
+    static constexpr int kNVec = C * kVecPerComp;
+    static constexpr int kIters = (kNVec + TILE - 1) / TILE;
+    static constexpr int kLdsBytes = C * TILE * (int)sizeof(T);
+    static_assert(TILE % kVec == 0, "tile must be a whole number of vectors");
+
+    struct Stage {
+        V v[kIters];
+    };
+
+    static __device__ __forceinline__ int64_t comp_off(int comp, int64_t sr, int64_t sc)
+    {
+        const int r = comp / Cc, c = comp - r * Cc;
+        return r * sr + c * sc;
+    }
+
+    // g = address of element tile0 of component (0, 0); left = elements from tile0 to the end
+    static __device__ __forceinline__ void issue(const T *__restrict__ g, int64_t sr, int64_t sc, int64_t left,
+                                                 Stage &st)
+    {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int q = tid + it * TILE;
+            if (kNVec % TILE == 0 || q < kNVec) {
+                const int comp = q / kVecPerComp, j = (q - comp * kVecPerComp) * kVec;
+                const T *p = g + comp_off(comp, sr, sc) + j;
+                if (j + kVec <= left) {
+                    st.v[it] = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+                } else {
+                    V v;
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k) v[k] = (j + k < left) ? p[k] : T(1);
+                    st.v[it] = v;
+                }
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void commit(unsigned char *lds, const Stage &st)
+    {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int q = tid + it * TILE;
+            if (kNVec % TILE == 0 || q < kNVec) *reinterpret_cast<V *>(lds + q * 16) = st.v[it];
+        }
+    }
+
+    static __device__ __forceinline__ void read_own(const unsigned char *lds, T (&r)[C])
+    {
+        const T *p = reinterpret_cast<const T *>(lds) + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) r[c] = p[c * TILE];
+    }
+
+    static __device__ __forceinline__ void write_own(unsigned char *lds, const T (&r)[C])
+    {
+        T *p = reinterpret_cast<T *>(lds) + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < C; ++c) p[c * TILE] = r[c];
+    }
+
+    static __device__ __forceinline__ void flush(T *__restrict__ g, int64_t sr, int64_t sc, int64_t left,
+                                                 const unsigned char *lds)
+    {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int q = tid + it * TILE;
+            if (kNVec % TILE == 0 || q < kNVec) {
+                const int comp = q / kVecPerComp, j = (q - comp * kVecPerComp) * kVec;
+                T *p = g + comp_off(comp, sr, sc) + j;
+                const V v = *reinterpret_cast<const V *>(lds + q * 16);
+                if (j + kVec <= left) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k)
+                        if (j + k < left) p[k] = v[k];
+                }
+            }
+        }
+    }
+};
+
 // Direct per-lane access for non-tiled operands (SoA fields, broadcast, strided).
 template <typename T, int C>
 __device__ __forceinline__ void direct_load(const Opnd &op, int64_t o, int64_t i, bool valid, T (&r)[C])
@@ -287,6 +386,19 @@ inline bool vec_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_o
     } else if (C > 1 && op->stride_col != 1) {
         return false;
     }
+    return true;
+}
+
+// Can the operand take the component-major tile path?  Unit stride along the inner batch
+// level and every component run (and every outer slab) 16-byte aligned.
+inline bool soa_ok(const nfm_operand *op, int C, int rows, size_t elem)
+{
+    if (op->ptr == nullptr || C < 2) return false;
+    const int64_t vec = 16 / (int64_t)elem;
+    if (reinterpret_cast<uintptr_t>(op->ptr) % 16 != 0) return false;
+    if (op->stride_inner != 1) return false;
+    if (op->stride_outer % vec != 0 || op->stride_col % vec != 0) return false;
+    if (rows > 1 && op->stride_row % vec != 0) return false;
     return true;
 }
 

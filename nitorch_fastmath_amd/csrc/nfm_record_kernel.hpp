@@ -31,11 +31,14 @@ struct Rec {
 using NoRec = Rec<0, 0>;
 
 // how an operand is moved (wave-uniform kernel argument Opnd::tiled)
-enum { MODE_STRIDED = 0, MODE_TILED = 1, MODE_VEC = 2 };
+enum { MODE_STRIDED = 0, MODE_TILED = 1, MODE_VEC = 2, MODE_SOA = 3 };
 
 template <typename T, class R, int TILE>
 struct RecIO {
     using IO = TileIO<T, R::Cs, TILE>;
+    using SO = SoaIO<T, (R::used ? R::R : 1), (R::used ? R::Cc : 1), TILE>;
+    static constexpr bool can_soa = R::used && R::C > 1;
+    static constexpr int soa_lds = can_soa ? SO::kLdsBytes : 0;
     // Records of exactly 4, 8 or 16 bytes that sit back to back in memory need no
     // transpose: one b32/b64/b128 access per lane is already a fully coalesced wave
     // access (measured on the 4x4 solve: the vec/out records moved this way instead of
@@ -44,6 +47,8 @@ struct RecIO {
     static constexpr bool can_vec = R::used && (R::C == 1 || R::C == 2 || R::C == 4) && RB <= 16;
     static constexpr bool can_tile = R::used && R::C > 1 && !can_vec;
     static constexpr int lds = can_tile ? IO::kLdsBytes : 0;
+    // region size that fits either LDS image of this operand (AoS-transposed or SoA)
+    static constexpr int lds_any = lds > soa_lds ? lds : soa_lds;
     static constexpr int pref = can_vec ? MODE_VEC : (can_tile ? MODE_TILED : MODE_STRIDED);
 };
 
@@ -110,6 +115,13 @@ struct RecLayout {
     static constexpr bool aliasC = !aliasA && !aliasB && C::can_tile && Op::RC::C == COUT;
     static constexpr int offO = aliasA ? offA : (aliasB ? offB : (aliasC ? offC : in_end));
     static constexpr int total = (aliasA || aliasB || aliasC) ? in_end : in_end + O::lds;
+    // layout of the run-time-mode (non-FAST) kernel: every region fits either image and the
+    // output has a region of its own (an SoA output image never aliases an AoS input image)
+    static constexpr int gA = 0;
+    static constexpr int gB = gA + A::lds_any;
+    static constexpr int gC = gB + B::lds_any;
+    static constexpr int gO = gC + C::lds_any;
+    static constexpr int gtotal = gO + O::lds_any;
 };
 
 template <typename T, class R>
@@ -149,6 +161,10 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     using RB = typename Op::RB;
     using RC = typename Op::RC;
     using RO = typename Op::RO;
+    using IA = RecIO<T, RA, Op::TILE>;
+    using IB = RecIO<T, RB, Op::TILE>;
+    using IC = RecIO<T, RC, Op::TILE>;
+    using IO_ = RecIO<T, RO, Op::TILE>;
     constexpr int TILE = Op::TILE;
     extern __shared__ __align__(16) unsigned char smem[];
 
@@ -159,75 +175,108 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     const int64_t left = n_inner - tile0; // batch elements from the tile start to the end
 
     T ra[RA::Cs], rb[RB::Cs], rc[RC::Cs], ro[RO::Cs];
-    typename L::A::IO::Stage sa;
-    typename L::B::IO::Stage sb;
-    typename L::C::IO::Stage sc;
 
-    const int ma = FAST ? L::A::pref : a.tiled, mb = FAST ? L::B::pref : b.tiled;
-    const int mc = FAST ? L::C::pref : c.tiled, mo = FAST ? L::O::pref : out.tiled;
-    const bool ta = L::A::can_tile && ma == MODE_TILED;
-    const bool tb = L::B::can_tile && mb == MODE_TILED;
-    const bool tc = L::C::can_tile && mc == MODE_TILED;
-    const bool to = L::O::can_tile && mo == MODE_TILED;
-    const bool va = L::A::can_vec && ma == MODE_VEC;
-    const bool vb = L::B::can_vec && mb == MODE_VEC;
-    const bool vc = L::C::can_vec && mc == MODE_VEC;
-    const bool vo = L::O::can_vec && mo == MODE_VEC;
+    // LDS regions and movement modes: compile-time constants in the FAST kernel
+    constexpr int oA = FAST ? L::offA : L::gA, oB = FAST ? L::offB : L::gB;
+    constexpr int oC = FAST ? L::offC : L::gC, oO = FAST ? L::offO : L::gO;
+    const int ma = FAST ? IA::pref : a.tiled, mb = FAST ? IB::pref : b.tiled;
+    const int mc = FAST ? IC::pref : c.tiled, mo = FAST ? IO_::pref : out.tiled;
     const bool use_c = RC::used && c.ptr != nullptr;
+    const bool tA = IA::can_tile && ma == MODE_TILED, tB = IB::can_tile && mb == MODE_TILED;
+    const bool tC = IC::can_tile && mc == MODE_TILED && use_c, tO = IO_::can_tile && mo == MODE_TILED;
+    const bool vA = IA::can_vec && ma == MODE_VEC, vB = IB::can_vec && mb == MODE_VEC;
+    const bool vC = IC::can_vec && mc == MODE_VEC, vO = IO_::can_vec && mo == MODE_VEC;
+    const bool sA = !FAST && IA::can_soa && ma == MODE_SOA, sB = !FAST && IB::can_soa && mb == MODE_SOA;
+    const bool sC = !FAST && IC::can_soa && mc == MODE_SOA && use_c, sO = !FAST && IO_::can_soa && mo == MODE_SOA;
 
-    // 1. all tiled global loads in flight
-    if constexpr (L::A::can_tile)
-        if (ta) L::A::IO::issue(reinterpret_cast<const T *>(a.ptr) + tile0 * RA::C, left * RA::C, sa);
-    if constexpr (L::B::can_tile)
-        if (tb) L::B::IO::issue(reinterpret_cast<const T *>(b.ptr) + tile0 * RB::C, left * RB::C, sb);
-    if constexpr (L::C::can_tile)
-        if (tc && use_c) L::C::IO::issue(reinterpret_cast<const T *>(c.ptr) + tile0 * RC::C, left * RC::C, sc);
+    typename IA::IO::Stage stA;
+    typename IB::IO::Stage stB;
+    typename IC::IO::Stage stC;
+    typename IA::SO::Stage sqA;
+    typename IB::SO::Stage sqB;
+    typename IC::SO::Stage sqC;
+
+    // 1. every 16-byte global load of the tile in flight (no waits in between)
+    if constexpr (IA::can_tile)
+        if (tA) IA::IO::issue(reinterpret_cast<const T *>(a.ptr) + tile0 * RA::C, left * RA::C, stA);
+    if constexpr (IB::can_tile)
+        if (tB) IB::IO::issue(reinterpret_cast<const T *>(b.ptr) + tile0 * RB::C, left * RB::C, stB);
+    if constexpr (IC::can_tile)
+        if (tC) IC::IO::issue(reinterpret_cast<const T *>(c.ptr) + tile0 * RC::C, left * RC::C, stC);
+    if constexpr (!FAST && IA::can_soa)
+        if (sA) IA::SO::issue(reinterpret_cast<const T *>(a.ptr) + o * a.so + tile0, a.sr, a.sc, left, sqA);
+    if constexpr (!FAST && IB::can_soa)
+        if (sB) IB::SO::issue(reinterpret_cast<const T *>(b.ptr) + o * b.so + tile0, b.sr, b.sc, left, sqB);
+    if constexpr (!FAST && IC::can_soa)
+        if (sC) IC::SO::issue(reinterpret_cast<const T *>(c.ptr) + o * c.so + tile0, c.sr, c.sc, left, sqC);
+
     // 2. per-lane loads: one packed access for back-to-back 4/8/16-byte records,
     //    element-wise strided access for everything else
     if constexpr (RA::used) {
-        if (va) {
-            if constexpr (L::A::can_vec) rec_vec_load<T, RA>(a, o, i, valid, ra);
-        } else if (!ta) rec_direct_load<T, RA>(a, o, i, valid, ra);
+        if (vA) {
+            if constexpr (IA::can_vec) rec_vec_load<T, RA>(a, o, i, valid, ra);
+        } else if (!tA && !sA) rec_direct_load<T, RA>(a, o, i, valid, ra);
     }
     if constexpr (RB::used) {
-        if (vb) {
-            if constexpr (L::B::can_vec) rec_vec_load<T, RB>(b, o, i, valid, rb);
-        } else if (!tb) rec_direct_load<T, RB>(b, o, i, valid, rb);
+        if (vB) {
+            if constexpr (IB::can_vec) rec_vec_load<T, RB>(b, o, i, valid, rb);
+        } else if (!tB && !sB) rec_direct_load<T, RB>(b, o, i, valid, rb);
     }
     if constexpr (RC::used) {
-        if (vc) {
-            if constexpr (L::C::can_vec) rec_vec_load<T, RC>(c, o, i, valid && use_c, rc);
-        } else if (!tc) rec_direct_load<T, RC>(c, o, i, valid && use_c, rc);
+        if (vC) {
+            if constexpr (IC::can_vec) rec_vec_load<T, RC>(c, o, i, valid && use_c, rc);
+        } else if (!tC && !sC) rec_direct_load<T, RC>(c, o, i, valid && use_c, rc);
     }
-    // 3. LDS transpose
-    if constexpr (L::A::can_tile)
-        if (ta) L::A::IO::commit(smem + L::offA, sa);
-    if constexpr (L::B::can_tile)
-        if (tb) L::B::IO::commit(smem + L::offB, sb);
-    if constexpr (L::C::can_tile)
-        if (tc && use_c) L::C::IO::commit(smem + L::offC, sc);
-    if (ta || tb || tc) __syncthreads();
-    if constexpr (L::A::can_tile)
-        if (ta) L::A::IO::read_own(smem + L::offA, ra);
-    if constexpr (L::B::can_tile)
-        if (tb) L::B::IO::read_own(smem + L::offB, rb);
-    if constexpr (L::C::can_tile)
-        if (tc && use_c) L::C::IO::read_own(smem + L::offC, rc);
+
+    // 3. LDS transpose: park the staged vectors, one barrier, every lane picks up its records
+    if constexpr (IA::can_tile)
+        if (tA) IA::IO::commit(smem + oA, stA);
+    if constexpr (IB::can_tile)
+        if (tB) IB::IO::commit(smem + oB, stB);
+    if constexpr (IC::can_tile)
+        if (tC) IC::IO::commit(smem + oC, stC);
+    if constexpr (!FAST && IA::can_soa)
+        if (sA) IA::SO::commit(smem + oA, sqA);
+    if constexpr (!FAST && IB::can_soa)
+        if (sB) IB::SO::commit(smem + oB, sqB);
+    if constexpr (!FAST && IC::can_soa)
+        if (sC) IC::SO::commit(smem + oC, sqC);
+    if (tA || tB || tC || sA || sB || sC) __syncthreads();
+    if constexpr (IA::can_tile)
+        if (tA) IA::IO::read_own(smem + oA, ra);
+    if constexpr (IB::can_tile)
+        if (tB) IB::IO::read_own(smem + oB, rb);
+    if constexpr (IC::can_tile)
+        if (tC) IC::IO::read_own(smem + oC, rc);
+    if constexpr (!FAST && IA::can_soa)
+        if (sA) IA::SO::read_own(smem + oA, ra);
+    if constexpr (!FAST && IB::can_soa)
+        if (sB) IB::SO::read_own(smem + oB, rb);
+    if constexpr (!FAST && IC::can_soa)
+        if (sC) IC::SO::read_own(smem + oC, rc);
 
     // 4. arithmetic
     Op::apply(ra, rb, rc, ro, prm);
 
     // 5. output
-    if constexpr (L::O::can_tile) {
-        if (to) {
-            L::O::IO::write_own(smem + L::offO, ro);
+    if constexpr (IO_::can_tile) {
+        if (tO) {
+            IO_::IO::write_own(smem + oO, ro);
             __syncthreads();
-            L::O::IO::flush(reinterpret_cast<T *>(out.ptr) + tile0 * RO::C, left * RO::C, smem + L::offO);
+            IO_::IO::flush(reinterpret_cast<T *>(out.ptr) + tile0 * RO::C, left * RO::C, smem + oO);
             return;
         }
     }
-    if constexpr (L::O::can_vec) {
-        if (vo) {
+    if constexpr (!FAST && IO_::can_soa) {
+        if (sO) {
+            IO_::SO::write_own(smem + oO, ro);
+            __syncthreads();
+            IO_::SO::flush(reinterpret_cast<T *>(out.ptr) + o * out.so + tile0, out.sr, out.sc, left, smem + oO);
+            return;
+        }
+    }
+    if constexpr (IO_::can_vec) {
+        if (vO) {
             rec_vec_store<T, RO>(out, o, i, valid, ro);
             return;
         }
@@ -255,11 +304,17 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     const bool tb = L::B::can_tile && tile_ok(b, RB::C, RB::R, RB::Cc, n_outer, n_inner, sizeof(T));
     const bool tc = L::C::can_tile && tile_ok(c, RC::C, RC::R, RC::Cc, n_outer, n_inner, sizeof(T));
     const bool to = L::O::can_tile && tile_ok(out, RO::C, RO::R, RO::Cc, n_outer, n_inner, sizeof(T));
-    const int ma = ta ? MODE_TILED : (L::A::can_vec && vec_ok(a, RA::C, RA::R, RA::Cc, n_outer, sizeof(T)) ? MODE_VEC : MODE_STRIDED);
-    const int mb = tb ? MODE_TILED : (L::B::can_vec && vec_ok(b, RB::C, RB::R, RB::Cc, n_outer, sizeof(T)) ? MODE_VEC : MODE_STRIDED);
-    const int mc = tc ? MODE_TILED : (L::C::can_vec && vec_ok(c, RC::C, RC::R, RC::Cc, n_outer, sizeof(T)) ? MODE_VEC : MODE_STRIDED);
-    const int mo = to ? MODE_TILED : (L::O::can_vec && vec_ok(out, RO::C, RO::R, RO::Cc, n_outer, sizeof(T)) ? MODE_VEC : MODE_STRIDED);
-    const bool any = ta || tb || tc || to;
+    auto mode = [&](bool tiled, bool can_vec, bool can_soa, const nfm_operand *op, int C, int R, int Cc) {
+        if (tiled) return (int)MODE_TILED;
+        if (can_vec && vec_ok(op, C, R, Cc, n_outer, sizeof(T))) return (int)MODE_VEC;
+        if (can_soa && soa_ok(op, C, R, sizeof(T))) return (int)MODE_SOA;
+        return (int)MODE_STRIDED;
+    };
+    const int ma = mode(ta, L::A::can_vec, L::A::can_soa, a, RA::C, RA::R, RA::Cc);
+    const int mb = mode(tb, L::B::can_vec, L::B::can_soa, b, RB::C, RB::R, RB::Cc);
+    const int mc = mode(tc, L::C::can_vec, L::C::can_soa, c, RC::C, RC::R, RC::Cc);
+    const int mo = mode(to, L::O::can_vec, L::O::can_soa, out, RO::C, RO::R, RO::Cc);
+    const bool any = ta || tb || tc || to || ma == MODE_SOA || mb == MODE_SOA || mc == MODE_SOA || mo == MODE_SOA;
     // FAST path: every used operand in its preferred mode (an absent C operand is fine)
     const bool c_absent = c->ptr == nullptr;
     const bool fast = n_outer == 1 && (!RA::used || ma == L::A::pref) && (!RB::used || mb == L::B::pref) &&
@@ -269,13 +324,13 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     const int64_t nblk = (n_inner + Op::TILE - 1) / Op::TILE;
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
     dim3 grid((unsigned)nblk, (unsigned)n_outer, 1), block(Op::TILE, 1, 1);
-    const size_t lds = any ? (size_t)L::total : 0;
+    const size_t lds = any ? (size_t)L::gtotal : 0;
     static bool attr_done = false; // > 64 KiB dynamic LDS needs an opt-in, once per kernel
-    if (L::total > 64 * 1024 && !attr_done) {
+    if (L::gtotal > 64 * 1024 && !attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
         hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
         attr_done = true;
     }
     if (fast)

@@ -82,6 +82,21 @@ def test_pivoting_and_layouts(dev, oracle, n):
     assert np.array_equal(r, oracle.batch_matvec(np.broadcast_to(a[0], a.shape), v))
 
 
+@pytest.mark.parametrize('n', [2, 3, 4, 8])
+def test_matrix_first_storage_tiles(dev, oracle, n):
+    """(n, n, B, S) storage viewed as (B, S, n, n): aligned component runs -> SoA tile path"""
+    rng = np.random.default_rng(40 + n)
+    Bn, Sn = 3, 340
+    a = rng.standard_normal((Bn, Sn, n, n)) + 6 * np.eye(n)
+    ad = t(a, dev).permute(2, 3, 0, 1).contiguous().permute(2, 3, 0, 1)
+    assert not ad.is_contiguous()
+    assert relerr(B().batchinv(ad).cpu().numpy(), oracle.batch_inv(a)) <= 1e-12
+    assert relerr(B().batchdet(ad).cpu().numpy(), oracle.batch_det(a)) <= 1e-12
+    v = rng.standard_normal((Bn, Sn, n))
+    vd = t(v, dev).permute(2, 0, 1).contiguous().permute(1, 2, 0)
+    assert np.array_equal(B().batchmatvec(ad, vd).cpu().numpy(), oracle.batch_matvec(a, v))
+
+
 def test_large_inverse_roundtrip(dev):
     """C3-shaped property check: inv(inv(A)) == A and A inv(A) == I on 1e6 8x8 fp64"""
     n = 1_000_000

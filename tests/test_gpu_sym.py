@@ -177,6 +177,41 @@ def test_inplace_and_eps_and_dtype(dev, oracle, dn, M):
         check(r, oracle.sym_solve(mat.astype(np.float64), vec.astype(np.float64)), 'f64', ex)
 
 
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [2, 4, 6, 8])
+def test_component_major_tiles(dev, oracle, dn, M):
+    """16-byte-aligned channel-first fields take the SoA tile path (MODE_SOA): vector loads of
+    every component run through LDS; sizes chosen with full and partial tiles"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    K = M * (M + 1) // 2
+    S = N().sym
+    ex = M <= 4
+    for B, X, Y in ((2, 40, 20), (1, 4, 3), (3, 16, 17)):        # X*Y % 4 == 0
+        mat, vec = spd_np(B * X * Y, M, dtype, 77 + M + X)
+        ref = oracle.sym_solve(mat, vec).reshape(B, X, Y, M)
+        refi = oracle.sym_invert(mat).reshape(B, X, Y, K)
+        refmv = oracle.sym_matvec(mat, vec, vec, -1).reshape(B, X, Y, M)
+        mat_cf = t(mat, dev).reshape(B, X, Y, K).movedim(-1, 1).contiguous().movedim(1, -1)
+        vec_cf = t(vec, dev).reshape(B, X, Y, M).movedim(-1, 1).contiguous().movedim(1, -1)
+        out_cf = torch.empty(B, M, X, Y, dtype=vec_cf.dtype, device=dev).movedim(1, -1)
+        S.sym_solve(mat_cf, vec_cf, out=out_cf)
+        check(out_cf, ref, dn, ex)
+        check(S.sym_solve(mat_cf, vec_cf), ref, dn, ex)                 # SoA in, AoS out
+        check(S.sym_solve(mat_cf, vec_cf.contiguous()), ref, dn, ex)    # mixed inputs
+        inv_cf = torch.empty(B, K, X, Y, dtype=vec_cf.dtype, device=dev).movedim(1, -1)
+        S.sym_invert(mat_cf, out=inv_cf)
+        check(inv_cf, refi, dn, ex)
+        check(S.sym_submatvec(vec_cf, mat_cf, vec_cf), refmv, dn, True)
+        v2 = vec_cf.clone(memory_format=torch.preserve_format)
+        S.sym_solve_(mat_cf, v2)                                        # in place on an SoA buffer
+        check(v2, ref, dn, ex)
+    # pure (K, n).T with n a multiple of 4 and not of the tile
+    n = 1000 + 4
+    mat, vec = spd_np(n, M, dtype, 5 + M)
+    ms, vs = t(mat, dev).t().contiguous().t(), t(vec, dev).t().contiguous().t()
+    check(S.sym_solve(ms, vs), oracle.sym_solve(mat, vec), dn, ex)
+
+
 def test_empty_and_errors(dev):
     S = N().sym
     r = S.sym_solve(torch.zeros(0, 10, device=dev), torch.zeros(0, 4, device=dev))
