@@ -162,6 +162,14 @@ int nfm_reduce_all(int dtype, int op, int out_dtype, int64_t n, const void *x, v
 int nfm_reduce_dim(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner,
                    const void *x, void *out, int64_t *idx, void *stream);
 
+/* One pass over a contiguous (outer, red, inner) view producing, per (outer, inner) entry,
+ * four doubles [count, sum(x - K), sum((x - K)^2), K] over the non-NaN elements of the
+ * reduced axis (K = a finite element of that slice, chosen by the kernel).  Feeds
+ * `nanmean` / `nanvar` / `nanstd` / `mean` / `var` / `std` (`reduce.py:513-763`).
+ * outer == inner == 1 takes the streaming full-reduction path and needs the workspace. */
+int nfm_reduce_moments(int dtype, int64_t outer, int64_t red, int64_t inner, const void *x,
+                       void *workspace, size_t workspace_bytes, double *out, void *stream);
+
 /* ------------------------------------------------------------------- qr ---- */
 /* Real dtypes.  Multi-output routines write ONE packed, contiguous output record per
  * matrix into `out` (n_outer * n_inner records, batch-major); the layout of the record

@@ -222,6 +222,122 @@ __global__ __launch_bounds__(256) void reduce_dim_k(const T *__restrict__ x, int
     }
 }
 
+// ---- one-pass moments: [count, sum(x - K), sum((x - K)^2), K] over the non-NaN elements,
+// K = the first finite element (a shift that removes the cancellation of the raw-moment
+// variance formula).  Feeds nanmean / nanvar / nanstd (reduce.py:553-763) in ONE pass over
+// memory instead of three.
+struct Mom {
+    double n, s, q;
+};
+__device__ __forceinline__ Mom mom_merge(Mom a, Mom b) { return {a.n + b.n, a.s + b.s, a.q + b.q}; }
+template <typename T>
+__device__ __forceinline__ void mom_fold(Mom &m, T v, double shift)
+{
+    const bool ok = v == v;
+    const double d = ok ? (double)v - shift : 0.0;
+    m.n += ok ? 1.0 : 0.0;
+    m.s += d;
+    m.q += d * d;
+}
+__device__ __forceinline__ Mom mom_wave(Mom m)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m.n += __shfl_xor(m.n, off, kWave);
+        m.s += __shfl_xor(m.s, off, kWave);
+        m.q += __shfl_xor(m.q, off, kWave);
+    }
+    return m;
+}
+template <typename T>
+__device__ __forceinline__ double pick_shift(const T *x, int64_t n, int64_t stride)
+{
+    // first finite value among the first few elements (uniform across the block)
+    double k = 0.0;
+    for (int64_t j = 0; j < n && j < 8; ++j) {
+        const double v = (double)x[j * stride];
+        if (v == v && v - v == 0.0) { k = v; break; }
+    }
+    return k;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kRedThreads) void moments_all_k1(const T *__restrict__ x, int64_t n,
+                                                               double *__restrict__ partial)
+{
+    __shared__ Mom lds[kRedThreads / kWave];
+    const double shift = pick_shift(x, n, 1);
+    Mom m = {0.0, 0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * kRedThreads;
+    for (int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x; q < n; q += stride) mom_fold(m, x[q], shift);
+    m = mom_wave(m);
+    if (threadIdx.x % kWave == 0) lds[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Mom r = lds[0];
+        for (int w = 1; w < kRedThreads / kWave; ++w) r = mom_merge(r, lds[w]);
+        partial[3 * blockIdx.x + 0] = r.n;
+        partial[3 * blockIdx.x + 1] = r.s;
+        partial[3 * blockIdx.x + 2] = r.q;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kRedThreads) void moments_all_k2(const double *__restrict__ partial, int nparts,
+                                                               const T *__restrict__ x, int64_t n, double *out)
+{
+    __shared__ Mom lds[kRedThreads / kWave];
+    Mom m = {0.0, 0.0, 0.0};
+    for (int p = threadIdx.x; p < nparts; p += kRedThreads)
+        m = mom_merge(m, Mom{partial[3 * p], partial[3 * p + 1], partial[3 * p + 2]});
+    m = mom_wave(m);
+    if (threadIdx.x % kWave == 0) lds[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Mom r = lds[0];
+        for (int w = 1; w < kRedThreads / kWave; ++w) r = mom_merge(r, lds[w]);
+        out[0] = r.n;
+        out[1] = r.s;
+        out[2] = r.q;
+        out[3] = pick_shift(x, n, 1);
+    }
+}
+
+// (outer, red, inner) moments; out is (outer, inner, 4) doubles
+template <typename T, bool WAVE_PER_ROW>
+__global__ __launch_bounds__(256) void moments_dim_k(const T *__restrict__ x, int64_t outer, int64_t red,
+                                                     int64_t inner, double *__restrict__ out)
+{
+    if constexpr (WAVE_PER_ROW) {
+        const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / kWave;
+        const int lane = threadIdx.x % kWave;
+        if (row >= outer) return;
+        const T *p = x + row * red;
+        const double shift = pick_shift(p, red, 1);
+        Mom m = {0.0, 0.0, 0.0};
+        for (int64_t r = lane; r < red; r += kWave) mom_fold(m, p[r], shift);
+        m = mom_wave(m);
+        if (lane == 0) {
+            out[4 * row + 0] = m.n;
+            out[4 * row + 1] = m.s;
+            out[4 * row + 2] = m.q;
+            out[4 * row + 3] = shift;
+        }
+    } else {
+        const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (e >= outer * inner) return;
+        const int64_t o = e / inner, i = e - o * inner;
+        const T *p = x + o * red * inner + i;
+        const double shift = pick_shift(p, red, inner);
+        Mom m = {0.0, 0.0, 0.0};
+        for (int64_t r = 0; r < red; ++r) mom_fold(m, p[r * inner], shift);
+        out[4 * e + 0] = m.n;
+        out[4 * e + 1] = m.s;
+        out[4 * e + 2] = m.q;
+        out[4 * e + 3] = shift;
+    }
+}
+
 template <typename T, int OP>
 static int reduce_all_t(int out_dtype, int64_t n, const void *x, void *ws, void *out, hipStream_t s)
 {
@@ -270,7 +386,7 @@ using namespace nfm;
 
 extern "C" {
 
-size_t nfm_reduce_workspace_bytes(void) { return (size_t)kRedBlocks * sizeof(double); }
+size_t nfm_reduce_workspace_bytes(void) { return (size_t)kRedBlocks * 3 * sizeof(double); }
 
 int nfm_reduce_all(int dtype, int op, int out_dtype, int64_t n, const void *x, void *workspace,
                    size_t workspace_bytes, void *out, void *stream)
@@ -305,6 +421,48 @@ int nfm_reduce_dim(int dtype, int op, int out_dtype, int64_t outer, int64_t red,
         NFM_SWITCH_OP(op, return (reduce_dim_t<double, OP>(out_dtype, outer, red, inner, x, out, idx, s)))
     }
     return NFM_EINVAL;
+}
+
+int nfm_reduce_moments(int dtype, int64_t outer, int64_t red, int64_t inner, const void *x, void *workspace,
+                       size_t workspace_bytes, double *out, void *stream)
+{
+    if (dtype != NFM_F32 && dtype != NFM_F64) return NFM_EDTYPE;
+    if (outer < 0 || red < 0 || inner < 0) return NFM_EINVAL;
+    if (outer == 0 || inner == 0) return NFM_OK;
+    if (out == nullptr || (red > 0 && x == nullptr)) return NFM_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (outer == 1 && inner == 1) { // full reduction: two-kernel streaming path
+        if (workspace == nullptr) return NFM_EINVAL;
+        if (workspace_bytes < nfm_reduce_workspace_bytes()) return NFM_EWORKSPACE;
+        double *partial = static_cast<double *>(workspace);
+        if (dtype == NFM_F32) {
+            hipLaunchKernelGGL((moments_all_k1<float>), dim3(kRedBlocks), dim3(kRedThreads), 0, s,
+                               static_cast<const float *>(x), red, partial);
+            hipLaunchKernelGGL((moments_all_k2<float>), dim3(1), dim3(kRedThreads), 0, s, partial, kRedBlocks,
+                               static_cast<const float *>(x), red, out);
+        } else {
+            hipLaunchKernelGGL((moments_all_k1<double>), dim3(kRedBlocks), dim3(kRedThreads), 0, s,
+                               static_cast<const double *>(x), red, partial);
+            hipLaunchKernelGGL((moments_all_k2<double>), dim3(1), dim3(kRedThreads), 0, s, partial, kRedBlocks,
+                               static_cast<const double *>(x), red, out);
+        }
+        return launch_status();
+    }
+    const bool wpr = inner == 1 && red >= 32;
+    const int64_t nblk = wpr ? (outer * kWave + 255) / 256 : (outer * inner + 255) / 256;
+    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    if (dtype == NFM_F32) {
+        if (wpr) hipLaunchKernelGGL((moments_dim_k<float, true>), dim3((unsigned)nblk), dim3(256), 0, s,
+                                    static_cast<const float *>(x), outer, red, inner, out);
+        else hipLaunchKernelGGL((moments_dim_k<float, false>), dim3((unsigned)nblk), dim3(256), 0, s,
+                                static_cast<const float *>(x), outer, red, inner, out);
+    } else {
+        if (wpr) hipLaunchKernelGGL((moments_dim_k<double, true>), dim3((unsigned)nblk), dim3(256), 0, s,
+                                    static_cast<const double *>(x), outer, red, inner, out);
+        else hipLaunchKernelGGL((moments_dim_k<double, false>), dim3((unsigned)nblk), dim3(256), 0, s,
+                                static_cast<const double *>(x), outer, red, inner, out);
+    }
+    return launch_status();
 }
 
 const char *nfm_strerror(int code)

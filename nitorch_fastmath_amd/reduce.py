@@ -186,23 +186,59 @@ def nansum(input, dim=None, keepdim=False, inplace=False, dtype=None, out=None):
     return sum(input, dim, keepdim, True, inplace, dtype, out)
 
 
-def _count(input, dim):
-    if dim is None:
-        return input.numel()
+def _moments(input, dim, keepdim):
+    """One pass: per output entry [count, sum(x - K), sum((x - K)^2), K] of the non-NaN values."""
+    input = torch.as_tensor(input)
+    dev = require_gpu(input)
+    no_grad_required(input)
+    code = dtype_code(input.dtype)
+    L = _lib.lib()
     nd = input.dim()
-    return _prod(input.shape[d if d >= 0 else nd + d] for d in ensure_list(dim))
+    if dim is None:
+        dims = list(range(nd))
+    else:
+        dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
+    shape = list(input.shape)
+    kept = [d for d in range(nd) if d not in dims]
+    consecutive = len(dims) > 0 and dims == list(range(dims[0], dims[0] + len(dims)))
+    if nd == 0:
+        x, outer, red, inner = input.reshape(1), 1, 1, 1
+    elif consecutive and input.is_contiguous():
+        x = input
+        outer, red, inner = _prod(shape[:dims[0]]), _prod(shape[d] for d in dims), _prod(shape[dims[-1] + 1:])
+    else:
+        x = input.permute(kept + dims).contiguous()
+        outer, red, inner = _prod([shape[d] for d in kept]), _prod(shape[d] for d in dims), 1
+    subshape = [shape[d] for d in kept]
+    out = torch.zeros(subshape + [4], dtype=torch.float64, device=dev)
+    ws, wsn = _workspace(dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.nfm_reduce_moments(code, outer, red, inner, x.data_ptr(), ws.data_ptr(), wsn,
+                                        out.data_ptr(), stream_ptr(dev)))
+    if keepdim:
+        out = out.reshape([1 if d in dims else s for d, s in enumerate(shape)] + [4])
+    return out[..., 0], out[..., 1], out[..., 2], out[..., 3], red
 
 
 def mean(input, dim=None, keepdim=False, omitnan=False, inplace=False, dtype=None, out=None):
     """Mean of a tensor (`reduce.py:513-550`)."""
     input = torch.as_tensor(input)
     odt = dtype or input.dtype
-    if omitnan:
-        s, _, _, _ = _reduce(_lib.RED_NANSUM, input, dim, keepdim, torch.float64)
-        w, _, _, _ = _reduce(_lib.RED_NANCOUNT, input, dim, keepdim, torch.float64)
-        return _deliver((s / w).to(odt), out)
-    s, _, _, _ = _reduce(_lib.RED_SUM, input, dim, keepdim, torch.float64)
-    return _deliver((s / _count(input, dim)).to(odt), out)
+    w, s, _, k, red = _moments(input, dim, keepdim)
+    m = k + s / w
+    if not omitnan:   # a NaN anywhere in the reduced block propagates (torch.mean)
+        m = torch.where(w == red, m, torch.full_like(m, float('nan')))
+        # infinities: the shifted sum cannot represent them; fall back to the plain sum there
+        bad = ~torch.isfinite(m) & (w == red)
+        if bool(bad.any()):
+            s2, _, _, _ = _reduce(_lib.RED_SUM, input, dim, keepdim, torch.float64)
+            m = torch.where(bad, s2 / red, m)
+    else:
+        bad = ~torch.isfinite(m) & (w > 0)
+        if bool(bad.any()):
+            s2, _, _, _ = _reduce(_lib.RED_NANSUM, input, dim, keepdim, torch.float64)
+            m = torch.where(bad, s2 / w, m)
+    return _deliver(m.to(odt), out)
 
 
 def nanmean(input, dim=None, keepdim=False, inplace=False, dtype=None, out=None):
@@ -211,22 +247,19 @@ def nanmean(input, dim=None, keepdim=False, inplace=False, dtype=None, out=None)
 
 
 def _nanvar64(input, dim, keepdim, unbiased):
-    s, _, _, _ = _reduce(_lib.RED_NANSUM, input, dim, keepdim, torch.float64)
-    q, _, _, _ = _reduce(_lib.RED_NANSUMSQ, input, dim, keepdim, torch.float64)
-    w, _, _, _ = _reduce(_lib.RED_NANCOUNT, input, dim, keepdim, torch.float64)
-    m = s / w
-    v = (q / w - m * m).clamp_min_(0)
+    w, s, q, _, red = _moments(input, dim, keepdim)
+    v = ((q - s * s / w) / w).clamp_min_(0)
     if unbiased:
         v = v * (w / (w - 1))       # `reduce.py:682-684`
-    return v, w
+    return v, w, red
 
 
 def var(input, dim=None, keepdim=False, unbiased=True, omitnan=False, inplace=False, dtype=None, out=None):
     """Variance of a tensor (`reduce.py:597-635`; the non-NaN form raises upstream, quirk Q13)."""
     input = torch.as_tensor(input)
-    v, w = _nanvar64(input, dim, keepdim, unbiased)
+    v, w, red = _nanvar64(input, dim, keepdim, unbiased)
     if not omitnan:   # a NaN anywhere in the reduced block propagates
-        v = torch.where(w == _count(input, dim), v, torch.full_like(v, float('nan')))
+        v = torch.where(w == red, v, torch.full_like(v, float('nan')))
     return _deliver(v.to(dtype or input.dtype), out)
 
 
