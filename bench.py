@@ -17,7 +17,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   "cpu_baseline": the CPU oracle (a C port of the reference's algorithm, OpenMP) timed on
                   this box's host cores on a bounded sample (rank 0, N = 1 only).
 Other workloads (parity-test configs, for profiling): --workload sym_solve6 | batchinv8 |
-nansum | nanmax | sym_invert3.
+nansum | nanmax | sym_invert3 | eig3.
 """
 import argparse
 import json
@@ -121,6 +121,24 @@ def make_workload(name, n_arg, device, rank, layout):
             import oracle as O
             m_h = mat.cpu().numpy()
             return time_cpu(lambda: O.sym_invert(m_h), n, budget_s), 'the whole batch'
+        w.cpu = cpu
+    elif name == 'eig3':
+        n = int(n_arg or 5e7)
+        g = torch.Generator(device=device).manual_seed(seed)
+        a = torch.randn(n, 3, 3, device=device, generator=g)
+        a = a + a.transpose(-1, -2)          # symmetric (Hessian-filter shaped workload)
+        w.units, w.bytes_per_unit, w.dtype = n, (9 + 3) * 4, 'f32'
+        w.desc = f'eig_sym 3x3 symmetric fp32 (eigenvalues), batch {n:.0e}'
+        w.metric, w.unit = '3x3 symmetric eigenvalue problems/sec', 'matrices/s'
+        w.step = lambda: N.eig_sym(a, check_finite=False)
+        w.kernel = 'rec_kernel<float, EigSymOp<float, 3, false>>'
+        w.check = lambda: (0.0, True)
+
+        def cpu(budget_s):
+            import oracle as O
+            ns = min(n, 2_000_000)
+            a_h = a[:ns].cpu().numpy()
+            return time_cpu(lambda: O.eig_sym(a_h), ns, budget_s), f'first {ns:.0e} matrices'
         w.cpu = cpu
     elif name == 'batchinv8':
         n = int(n_arg or 1e7)

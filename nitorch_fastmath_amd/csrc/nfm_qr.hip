@@ -6,6 +6,12 @@
 #include "nfm_record_kernel.hpp"
 #include "nfm_qr_core.hpp"
 
+// This file is compiled four times (-DNFM_QR_PART=0..3), one object per group of entry
+// points, so that the heavy template instantiations build in parallel.
+#ifndef NFM_QR_PART
+#error "compile with -DNFM_QR_PART=0..3"
+#endif
+
 namespace nfm {
 
 constexpr int upack_len(int N) { return N > 2 ? (N - 2) * (N - 1) : 0; }
@@ -432,6 +438,7 @@ using namespace nfm;
 
 extern "C" {
 
+#if NFM_QR_PART == 3
 int nfm_qr_givens(int dtype, int64_t n_outer, int64_t n_inner, const nfm_operand *x, const nfm_operand *y, void *out,
                   void *stream)
 {
@@ -444,7 +451,9 @@ int nfm_qr_givens(int dtype, int64_t n_outer, int64_t n_inner, const nfm_operand
     return dtype == NFM_F32 ? rec_launch<float, GivensOp<float>>(x, y, nullptr, &o, n_outer, n_inner, p, stream)
                             : rec_launch<double, GivensOp<double>>(x, y, nullptr, &o, n_outer, n_inner, p, stream);
 }
+#endif
 
+#if NFM_QR_PART == 3
 int nfm_qr_givens_apply(int dtype, int N, int side, int i, int j, int64_t n_outer, int64_t n_inner,
                         const nfm_operand *a, const nfm_operand *c, const nfm_operand *s, void *stream)
 {
@@ -463,7 +472,9 @@ int nfm_qr_givens_apply(int dtype, int N, int side, int i, int j, int64_t n_oute
                            make_opnd(a, 0), make_opnd(c, 0), make_opnd(s, 0), n_inner, N, i, j, side);
     return launch_status();
 }
+#endif
 
+#if NFM_QR_PART == 3
 int nfm_qr_householder(int dtype, int N, int basis, int64_t n_outer, int64_t n_inner, const nfm_operand *x,
                        void *out, void *stream)
 {
@@ -475,7 +486,9 @@ int nfm_qr_householder(int dtype, int N, int basis, int64_t n_outer, int64_t n_i
     return dtype == NFM_F32 ? householder_t<float>(N, n_outer, n_inner, x, out, p, stream)
                             : householder_t<double>(N, n_outer, n_inner, x, out, p, stream);
 }
+#endif
 
+#if NFM_QR_PART == 3
 int nfm_qr_householder_apply(int dtype, int N, int m, int side, int64_t n_outer, int64_t n_inner,
                              const nfm_operand *a, const nfm_operand *u, void *stream)
 {
@@ -493,7 +506,9 @@ int nfm_qr_householder_apply(int dtype, int N, int m, int side, int64_t n_outer,
                            make_opnd(a, 0), make_opnd(u, 0), n_inner, N, m, side);
     return launch_status();
 }
+#endif
 
+#if NFM_QR_PART == 1
 int nfm_qr_hessenberg(int dtype, int N, int sym, int upper, int with_u, int64_t n_outer, int64_t n_inner,
                       const nfm_operand *a, void *out, void *stream)
 {
@@ -504,7 +519,9 @@ int nfm_qr_hessenberg(int dtype, int N, int sym, int upper, int with_u, int64_t 
     return dtype == NFM_F32 ? hess_t<float>(N, sym, with_u, n_outer, n_inner, a, out, p, stream)
                             : hess_t<double>(N, sym, with_u, n_outer, n_inner, a, out, p, stream);
 }
+#endif
 
+#if NFM_QR_PART == 2
 int nfm_qr_qr_hessenberg(int dtype, int N, int64_t n_outer, int64_t n_inner, const nfm_operand *h, void *out,
                          void *stream)
 {
@@ -515,7 +532,9 @@ int nfm_qr_qr_hessenberg(int dtype, int N, int64_t n_outer, int64_t n_inner, con
     return dtype == NFM_F32 ? qr_hess_t<float>(N, n_outer, n_inner, h, out, p, stream)
                             : qr_hess_t<double>(N, n_outer, n_inner, h, out, p, stream);
 }
+#endif
 
+#if NFM_QR_PART == 2
 int nfm_qr_rq_hessenberg(int dtype, int N, int sym, int64_t n_outer, int64_t n_inner, const nfm_operand *h,
                          const nfm_operand *u, void *out, void *stream)
 {
@@ -527,7 +546,9 @@ int nfm_qr_rq_hessenberg(int dtype, int N, int sym, int64_t n_outer, int64_t n_i
     return dtype == NFM_F32 ? rq_hess_t<float>(N, n_outer, n_inner, h, u, out, p, stream)
                             : rq_hess_t<double>(N, n_outer, n_inner, h, u, out, p, stream);
 }
+#endif
 
+#if NFM_QR_PART == 0
 int nfm_qr_eig_sym(int dtype, int N, int upper, int with_u, int max_iter, double tol, int64_t n_outer,
                    int64_t n_inner, const nfm_operand *a, void *out, void *stream)
 {
@@ -539,5 +560,6 @@ int nfm_qr_eig_sym(int dtype, int N, int upper, int with_u, int max_iter, double
     return dtype == NFM_F32 ? eig_sym_t<float>(N, with_u, n_outer, n_inner, a, out, p, stream)
                             : eig_sym_t<double>(N, with_u, n_outer, n_inner, a, out, p, stream);
 }
+#endif
 
 } // extern "C"
