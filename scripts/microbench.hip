@@ -81,6 +81,25 @@ __global__ __launch_bounds__(256) void copy_kernel(const f4 *__restrict__ mat, c
     }
 }
 
+// ---- 50/50 read/write ceiling: plain streaming copy, 4 x 16 B in flight per lane
+template <bool NT>
+__global__ __launch_bounds__(256) void copy5050_kernel(const f4 *__restrict__ in, f4 *__restrict__ out, int64_t nvec)
+{
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (q + 3 * stride >= nvec) return;
+    f4 v0, v1, v2, v3;
+    if (NT) {
+        v0 = __builtin_nontemporal_load(in + q); v1 = __builtin_nontemporal_load(in + q + stride);
+        v2 = __builtin_nontemporal_load(in + q + 2 * stride); v3 = __builtin_nontemporal_load(in + q + 3 * stride);
+        __builtin_nontemporal_store(v0, out + q); __builtin_nontemporal_store(v1, out + q + stride);
+        __builtin_nontemporal_store(v2, out + q + 2 * stride); __builtin_nontemporal_store(v3, out + q + 3 * stride);
+    } else {
+        v0 = in[q]; v1 = in[q + stride]; v2 = in[q + 2 * stride]; v3 = in[q + 3 * stride];
+        out[q] = v0; out[q + stride] = v1; out[q + 2 * stride] = v2; out[q + 3 * stride] = v3;
+    }
+}
+
 // ---- direct: every lane loads its own 40-byte record (x4, x4, x2), no LDS
 template <int WAVES, bool NT>
 __global__ __launch_bounds__(256, WAVES) void direct_kernel(const float *__restrict__ mat,
@@ -207,6 +226,62 @@ __global__ __launch_bounds__(TILE, WAVES) void pipe_kernel(const float *__restri
     }
 }
 
+// ---- batchinv 8x8 fp64 experiments: PASSES sub-tiles through a smaller LDS image
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <int PASSES, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void binv_kernel(const double *__restrict__ a, double *__restrict__ out,
+                                                         int64_t n)
+{
+    constexpr int RPP = 64 / PASSES;          // records per pass
+    constexpr int IPP = 32 / PASSES;          // staged vectors (per lane) per pass
+    __shared__ __align__(16) d2 lds[RPP * 33]; // 32 slots per record + 1 pad
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    if (r0 + 64 > n) return;
+    const d2 *pa = (const d2 *)(a + r0 * 64);
+    d2 st[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) st[k] = __builtin_nontemporal_load(pa + t + 64 * k);
+    double m[8][8];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        if (p > 0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < IPP; ++k) {
+            const int row = 2 * k + t / 32, col = t % 32;
+            lds[row * 33 + col] = st[p * IPP + k];
+        }
+        __syncthreads();
+        if (t / RPP == p) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                d2 v = lds[(t % RPP) * 33 + j];
+                m[j / 4][(j % 4) * 2] = v[0];
+                m[j / 4][(j % 4) * 2 + 1] = v[1];
+            }
+        }
+    }
+    gj_inverse<double, 8>(m);
+    d2 *po = (d2 *)(out + r0 * 64);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        __syncthreads();
+        if (t / RPP == p) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                d2 v = {m[j / 4][(j % 4) * 2], m[j / 4][(j % 4) * 2 + 1]};
+                lds[(t % RPP) * 33 + j] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < IPP; ++k) {
+            const int row = 2 * k + t / 32, col = t % 32;
+            __builtin_nontemporal_store(lds[row * 33 + col], po + t + 64 * (p * IPP + k));
+        }
+    }
+}
+
 struct Variant {
     std::string name;
     std::function<void()> run;
@@ -271,6 +346,13 @@ int main(int argc, char **argv)
     addb("lib sym_invert 4x4 f32", n * 80.0, [&] { nfm_operand oi = {mat6, 0, 10, 0, 1}; nfm_sym_invert(NFM_F32, 4, 0, 1, n, &om, &oi, nullptr); });
     addb("lib batchinv 8x8 f64", n8 * 1024.0, [&] { nfm_batch_inv(NFM_F64, 8, 0, 1, n8, &oa8, &oo8, nullptr); });
     addb("lib sym_invert 3x3 f64", n3 * 96.0, [&] { nfm_sym_invert(NFM_F64, 3, 0, 1, n3, &om3, &oo3, nullptr); });
+#define BINV(P, W) addb("binv8 f64 passes" #P " w" #W, n8 * 1024.0, [&] { hipLaunchKernelGGL((binv_kernel<P, W>), dim3(n8 / 64), dim3(64), 0, 0, a8, o8, n8); })
+    BINV(1, 1); BINV(1, 2); BINV(2, 1); BINV(2, 2); BINV(2, 3); BINV(4, 1); BINV(4, 2); BINV(4, 3);
+    {
+        const int64_t nvec = n8 * 512 / 16;   // the 5.12 GB batchinv input, copied to its output buffer
+        addb("copy 50/50 ceiling nt", 2.0 * nvec * 16, [&, nvec] { hipLaunchKernelGGL((copy5050_kernel<true>), dim3(nvec / 1024), dim3(256), 0, 0, (const f4 *)a8, (f4 *)o8, nvec + 1); });
+        addb("copy 50/50 ceiling plain", 2.0 * nvec * 16, [&, nvec] { hipLaunchKernelGGL((copy5050_kernel<false>), dim3(nvec / 1024), dim3(256), 0, 0, (const f4 *)a8, (f4 *)o8, nvec + 1); });
+    }
     addb("hipMemcpy D2D 4 GB (2x bytes)", 2.0 * n * 40, [&] { hipMemcpyAsync(mat6, mat, n * 40, hipMemcpyDeviceToDevice, 0); });
 
     hipEvent_t e0, e1;
