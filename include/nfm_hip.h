@@ -108,6 +108,12 @@ int nfm_sym_to_full(int dtype, int M, int64_t n_outer, int64_t n_inner, const nf
 int nfm_sym_outer(int dtype, int M, int64_t n_outer, int64_t n_inner, const nfm_operand *x,
                   const nfm_operand *out, void *stream);
 
+/* out_ii = x_i y_i, out_ij = x_i y_j + x_j y_i (i < j), negated when neg != 0: the pull-back
+ * of the full-matrix cotangent x y^T onto compact storage.  No reference counterpart: it is
+ * the building block of the backward passes of sym_matvec / sym_solve (autograd). */
+int nfm_sym_outer2(int dtype, int M, int neg, int64_t n_outer, int64_t n_inner, const nfm_operand *x,
+                   const nfm_operand *y, const nfm_operand *out, void *stream);
+
 /* compact J^T H J, `sym_matmul` `_impl/sym.py:637-670`; jac is (K x D) full, hess compact
  * (hess_kind NFM_MAT_SYM) or diagonal (NFM_MAT_DIAG).  For K == D in {2, 3} the reference
  * evaluates J H J^T (quirk Q16, `jhj2`/`jhj3` `_impl/sym.py:540-597`); so does this. */

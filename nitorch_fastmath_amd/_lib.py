@@ -37,6 +37,7 @@ SIGNATURES = {
     'nfm_sym_det': [_i, _i, _i64, _i64, _op, _op, _vp],
     'nfm_sym_to_full': [_i, _i, _i64, _i64, _op, _op, _vp],
     'nfm_sym_outer': [_i, _i, _i64, _i64, _op, _op, _vp],
+    'nfm_sym_outer2': [_i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_sym_matmul': [_i, _i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_batch_inv': [_i, _i, _i, _i64, _i64, _op, _op, _vp],
     'nfm_batch_det': [_i, _i, _i64, _i64, _op, _op, _vp],

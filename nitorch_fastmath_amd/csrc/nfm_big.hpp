@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kWave) void big_lu_kernel(BigArgs g)
 }
 
 // element-wise style ops that need no working matrix: direct strided global access
-enum { BIGE_MATVEC = 0, BIGE_TOFULL = 1, BIGE_OUTER = 2, BIGE_DIVDIAG = 3, BIGE_GMATVEC = 4, BIGE_MATMUL = 5 };
+enum { BIGE_MATVEC = 0, BIGE_TOFULL = 1, BIGE_OUTER = 2, BIGE_DIVDIAG = 3, BIGE_GMATVEC = 4, BIGE_MATMUL = 5, BIGE_OUTER2 = 6 };
 
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void big_elem_kernel(BigArgs g)
@@ -212,6 +212,16 @@ __global__ __launch_bounds__(256) void big_elem_kernel(BigArgs g)
         T *f = opnd_ptr_w<T>(g.out, o, i);
         for (int r = 0; r < N; ++r)
             for (int c = r; c < N; ++c) f[sym_idx(N, r, c) * g.out.sc] = x[r * g.a.sc] * x[c * g.a.sc];
+    } else if (OP == BIGE_OUTER2) { // x y^T + y x^T pulled back onto compact storage
+        const T *x = opnd_ptr<T>(g.a, o, i);
+        const T *y = opnd_ptr<T>(g.b, o, i);
+        T *f = opnd_ptr_w<T>(g.out, o, i);
+        for (int r = 0; r < N; ++r)
+            for (int c = r; c < N; ++c) {
+                const T v = (r == c) ? x[r * g.a.sc] * y[r * g.b.sc]
+                                     : x[r * g.a.sc] * y[c * g.b.sc] + x[c * g.a.sc] * y[r * g.b.sc];
+                f[sym_idx(N, r, c) * g.out.sc] = g.mode ? -v : v;
+            }
     } else if (OP == BIGE_DIVDIAG) { // solve with a diagonal / scaled-identity matrix
         const T *m = opnd_ptr<T>(g.a, o, i);
         const T *v = opnd_ptr<T>(g.b, o, i);
@@ -340,6 +350,14 @@ int big_sym_outer(int M, int64_t no, int64_t ni, const nfm_operand *x, const nfm
 {
     BigArgs g = big_args(x, nullptr, nullptr, out, ni, M, M, NFM_MAT_SYM, 0, nullptr);
     return big_elem_launch<T, BIGE_OUTER>(g, no, ni, stream);
+}
+
+template <typename T>
+int big_sym_outer2(int M, int neg, int64_t no, int64_t ni, const nfm_operand *x, const nfm_operand *y,
+                   const nfm_operand *out, void *stream)
+{
+    BigArgs g = big_args(x, y, nullptr, out, ni, M, M, NFM_MAT_SYM, neg, nullptr);
+    return big_elem_launch<T, BIGE_OUTER2>(g, no, ni, stream);
 }
 
 template <typename T>

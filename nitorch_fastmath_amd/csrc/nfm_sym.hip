@@ -213,6 +213,35 @@ struct OuterOp {
     }
 };
 
+// ---- x y^T + y x^T in "gradient of a compact matrix" convention ------------------------
+// out_ii = x_i y_i, out_ij = x_i y_j + x_j y_i (i < j): the pull-back of a full-matrix
+// cotangent x y^T onto compact storage, where one stored entry stands for both (i, j) and
+// (j, i).  Used by the backward passes of sym_matvec / sym_solve; `neg` flips the sign.
+struct Outer2Params {
+    int neg;
+};
+
+template <typename T, int M>
+struct Outer2Op {
+    using RA = Rec<1, M>;
+    using RB = Rec<1, M>;
+    using RC = NoRec;
+    using RO = Rec<1, sym_k(M)>;
+    using Params = Outer2Params;
+    static constexpr int TILE = pick_tile((2 * M + RO::C) * (int)sizeof(T) + 48);
+    static __device__ __forceinline__ void apply(const T (&x)[M], const T (&y)[M], const T (&)[1], T (&r)[RO::Cs],
+                                                 const Params &p)
+    {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = i; j < M; ++j) {
+                const T v = (i == j) ? x[i] * y[i] : x[i] * y[j] + x[j] * y[i];
+                r[sym_idx(M, i, j)] = p.neg ? -v : v;
+            }
+    }
+};
+
 // ---- J^T H J (compact) ---------------------------------------------------------------
 // _impl/sym.py:531-670.  jac (K x D) row-major record, hess compact (HK = SYM) or
 // diagonal (HK = DIAG).  K == D in {1, 2, 3} with a compact hess follow jhj1/2/3 to the
@@ -401,6 +430,16 @@ static int sym_outer_t(int M, int64_t no, int64_t ni, const nfm_operand *x, cons
     return NFM_EINVAL;
 }
 
+template <typename T>
+static int sym_outer2_t(int M, int neg, int64_t no, int64_t ni, const nfm_operand *x, const nfm_operand *y,
+                        const nfm_operand *out, void *stream)
+{
+    if (M > 8) return big_sym_outer2<T>(M, neg, no, ni, x, y, out, stream);
+    Outer2Params p{neg};
+    NFM_SWITCH_M8(M, return (rec_launch<T, Outer2Op<T, M>>(x, y, nullptr, out, no, ni, p, stream)))
+    return NFM_EINVAL;
+}
+
 template <typename T, int HK>
 static int sym_matmul_t(int K, int D, int64_t no, int64_t ni, const nfm_operand *jac, const nfm_operand *hess,
                         const nfm_operand *out, void *stream)
@@ -509,6 +548,20 @@ int nfm_sym_outer(int dtype, int M, int64_t n_outer, int64_t n_inner, const nfm_
     if ((rc = check_operand(out, dtype, nonempty))) return rc;
     return dtype == NFM_F32 ? sym_outer_t<float>(M, n_outer, n_inner, x, out, stream)
                             : sym_outer_t<double>(M, n_outer, n_inner, x, out, stream);
+}
+
+int nfm_sym_outer2(int dtype, int M, int neg, int64_t n_outer, int64_t n_inner, const nfm_operand *x,
+                   const nfm_operand *y, const nfm_operand *out, void *stream)
+{
+    int rc = check_common(dtype, n_outer, n_inner);
+    if (rc) return rc;
+    if (M < 1 || M > NFM_MAX_DIM) return NFM_ESIZE;
+    const bool nonempty = n_outer > 0 && n_inner > 0;
+    if ((rc = check_operand(x, dtype, nonempty))) return rc;
+    if ((rc = check_operand(y, dtype, nonempty))) return rc;
+    if ((rc = check_operand(out, dtype, nonempty))) return rc;
+    return dtype == NFM_F32 ? sym_outer2_t<float>(M, neg ? 1 : 0, n_outer, n_inner, x, y, out, stream)
+                            : sym_outer2_t<double>(M, neg ? 1 : 0, n_outer, n_inner, x, y, out, stream);
 }
 
 int nfm_sym_matmul(int dtype, int K, int D, int hess_kind, int64_t n_outer, int64_t n_inner,

@@ -106,6 +106,12 @@ def eig_sym(a, compute_u=False, upper=True, inplace=False, check_finite=True, ma
     s : `(..., m) tensor`
     u : `(..., m, m) tensor`, optional
     """
+    from ._autograd import EigSymFn, needs_grad
+    if needs_grad(a):
+        a = torch.as_tensor(a)
+        _check_finite(check_finite, a.detach())
+        _check_square(a)
+        return EigSymFn.apply(a, bool(compute_u), bool(upper), int(max_iter), float(tol))
     dev, dtype, (a,) = _prep(a)
     _check_finite(check_finite, a)
     _check_square(a)

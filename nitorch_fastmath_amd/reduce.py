@@ -28,6 +28,15 @@ from ._dispatch import dtype_code, no_grad_required, require_gpu, stream_ptr
 from .utils import ensure_list, ind2sub
 
 
+def _needs_grad(t):
+    return torch.is_grad_enabled() and t.requires_grad
+
+
+def _SumFn():
+    from ._autograd import SumFn
+    return SumFn
+
+
 def _prod(xs):
     p = 1
     for x in xs:
@@ -176,6 +185,8 @@ def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_
 def sum(input, dim=None, keepdim=False, omitnan=False, inplace=False, dtype=None, out=None):
     """Sum of a tensor (`reduce.py:431-468`); `dtype` is the accumulator/output dtype."""
     input = torch.as_tensor(input)
+    if _needs_grad(input):
+        return _deliver(_SumFn().apply(input, dim, keepdim, omitnan, False, dtype), out)
     op = _lib.RED_NANSUM if omitnan else _lib.RED_SUM
     val, _, _, _ = _reduce(op, input, dim, keepdim, dtype or input.dtype)
     return _deliver(val, out)
@@ -223,6 +234,8 @@ def _moments(input, dim, keepdim):
 def mean(input, dim=None, keepdim=False, omitnan=False, inplace=False, dtype=None, out=None):
     """Mean of a tensor (`reduce.py:513-550`)."""
     input = torch.as_tensor(input)
+    if _needs_grad(input):
+        return _deliver(_SumFn().apply(input, dim, keepdim, omitnan, True, dtype), out)
     odt = dtype or input.dtype
     w, s, _, k, red = _moments(input, dim, keepdim)
     m = k + s / w

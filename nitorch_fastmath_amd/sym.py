@@ -113,6 +113,15 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
     return out
 
 
+def _matvec(mode, inp, mat, vec, dtype, out):
+    from ._autograd import SymMatvecFn, needs_grad
+    if needs_grad(inp, mat, vec):
+        if out is not None:
+            raise RuntimeError('out= is not supported for tensors that require grad')
+        return SymMatvecFn.apply(mode, inp, torch.as_tensor(mat), torch.as_tensor(vec), dtype)
+    return _matvec_impl(mode, inp, mat, vec, dtype, out)
+
+
 def sym_matvec(mat, vec, dtype=None, out=None):
     r"""Matrix-vector product with a compact symmetric matrix: `mat @ vec`.
 
@@ -131,12 +140,12 @@ def sym_matvec(mat, vec, dtype=None, out=None):
     -------
     matvec : `(..., M) tensor`
     """
-    return _matvec_impl(0, None, mat, vec, dtype, out)
+    return _matvec(0, None, mat, vec, dtype, out)
 
 
 def sym_addmatvec(inp, mat, vec, dtype=None, out=None):
     """`inp + mat @ vec` (reference name list `sym.py:31`)."""
-    return _matvec_impl(+1, inp, mat, vec, dtype, out)
+    return _matvec(+1, inp, mat, vec, dtype, out)
 
 
 def sym_addmatvec_(inp, mat, vec):
@@ -147,7 +156,7 @@ def sym_addmatvec_(inp, mat, vec):
 
 def sym_submatvec(inp, mat, vec, dtype=None, out=None):
     """`inp - mat @ vec` (reference name list `sym.py:32`)."""
-    return _matvec_impl(-1, inp, mat, vec, dtype, out)
+    return _matvec(-1, inp, mat, vec, dtype, out)
 
 
 def sym_submatvec_(inp, mat, vec):
@@ -182,6 +191,11 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     -------
     result : `(..., M) tensor`
     """
+    from ._autograd import SymSolveFn, needs_grad
+    if needs_grad(mat, vec):
+        if out is not None:
+            raise RuntimeError('out= is not supported for tensors that require grad')
+        return SymSolveFn.apply(torch.as_tensor(mat), torch.as_tensor(vec), eps, dtype)
     dev, dtype, (mat, vec) = _prep(dtype, mat, vec)
     N = vec.shape[-1]
     _check_order(N)

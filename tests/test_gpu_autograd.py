@@ -1,0 +1,165 @@
+"""Autograd through the HIP kernels, checked against torch's own autograd of dense fp64
+equivalents on the CPU (independent implementation)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def N():
+    import nitorch_fastmath_amd as N_
+    return N_
+
+
+def to_full(c, M):
+    """differentiable compact -> full in plain torch (CPU reference)"""
+    rows = [[None] * M for _ in range(M)]
+    k = M
+    for i in range(M):
+        rows[i][i] = c[..., i]
+    for i in range(M):
+        for j in range(i + 1, M):
+            rows[i][j] = rows[j][i] = c[..., k]
+            k += 1
+    return torch.stack([torch.stack(r, -1) for r in rows], -2)
+
+
+def spd(n, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn(n, M, M, dtype=torch.float64, generator=g)
+    A = G @ G.transpose(-1, -2) / M + torch.eye(M, dtype=torch.float64)
+    cols = [A[:, i, i] for i in range(M)] + [A[:, i, j] for i in range(M) for j in range(i + 1, M)]
+    return torch.stack(cols, -1), torch.randn(n, M, dtype=torch.float64, generator=g), torch.randn(n, M, dtype=torch.float64, generator=g)
+
+
+@pytest.mark.parametrize('M', [2, 3, 4, 6, 12])
+def test_sym_solve_and_matvec_backward(dev, M):
+    n = 50
+    mat, vec, w = spd(n, M, M)
+    # CPU reference
+    mc, vc = mat.clone().requires_grad_(), vec.clone().requires_grad_()
+    x = torch.linalg.solve(to_full(mc, M), vc.unsqueeze(-1)).squeeze(-1)
+    (x * w).sum().backward()
+    md, vd = mat.to(dev).requires_grad_(), vec.to(dev).requires_grad_()
+    xd = N().sym_solve(md, vd)
+    assert xd.requires_grad
+    (xd * w.to(dev)).sum().backward()
+    assert torch.allclose(xd.detach().cpu(), x.detach(), rtol=1e-10, atol=1e-12)
+    assert torch.allclose(vd.grad.cpu(), vc.grad, rtol=1e-9, atol=1e-11)
+    assert torch.allclose(md.grad.cpu(), mc.grad, rtol=1e-9, atol=1e-11)
+    # matvec / addmatvec / submatvec
+    for mode, fn in ((0, N().sym_matvec), (1, N().sym_addmatvec), (-1, N().sym_submatvec)):
+        mc, vc, ic = mat.clone().requires_grad_(), vec.clone().requires_grad_(), w.clone().requires_grad_()
+        y = (to_full(mc, M) @ vc.unsqueeze(-1)).squeeze(-1)
+        y = y if mode == 0 else ic + mode * y
+        (y * y).sum().backward()
+        md, vd, idd = mat.to(dev).requires_grad_(), vec.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+        yd = fn(md, vd) if mode == 0 else fn(idd, md, vd)
+        (yd * yd).sum().backward()
+        assert torch.allclose(md.grad.cpu(), mc.grad, rtol=1e-9, atol=1e-11)
+        assert torch.allclose(vd.grad.cpu(), vc.grad, rtol=1e-9, atol=1e-11)
+        if mode:
+            assert torch.allclose(idd.grad.cpu(), ic.grad, rtol=1e-9, atol=1e-11)
+
+
+def test_sym_solve_backward_broadcast_and_kinds(dev):
+    M, n = 3, 20
+    mat, vec, w = spd(n, M, 9)
+    # one matrix broadcast against many vectors: the matrix gradient is summed over the batch
+    mc, vc = mat[:1].clone().requires_grad_(), vec.clone().requires_grad_()
+    x = torch.linalg.solve(to_full(mc, M).expand(n, M, M), vc.unsqueeze(-1)).squeeze(-1)
+    (x * w).sum().backward()
+    md, vd = mat[:1].to(dev).requires_grad_(), vec.to(dev).requires_grad_()
+    (N().sym_solve(md, vd) * w.to(dev)).sum().backward()
+    assert md.grad.shape == (1, 6)
+    assert torch.allclose(md.grad.cpu(), mc.grad, rtol=1e-9, atol=1e-11)
+    assert torch.allclose(vd.grad.cpu(), vc.grad, rtol=1e-9, atol=1e-11)
+    # diagonal and full matrix kinds
+    dc, vc = mat[:, :M].clone().requires_grad_(), vec.clone().requires_grad_()
+    ((vc / dc) * w).sum().backward()
+    dd, vd = mat[:, :M].to(dev).contiguous().requires_grad_(), vec.to(dev).requires_grad_()
+    (N().sym_solve(dd, vd) * w.to(dev)).sum().backward()
+    assert torch.allclose(dd.grad.cpu(), dc.grad, rtol=1e-9) and torch.allclose(vd.grad.cpu(), vc.grad, rtol=1e-9)
+    g = torch.Generator().manual_seed(1)
+    F = torch.randn(n, M, M, dtype=torch.float64, generator=g) + 4 * torch.eye(M, dtype=torch.float64)
+    fc, vc = F.clone().requires_grad_(), vec.clone().requires_grad_()
+    (torch.linalg.solve(fc, vc.unsqueeze(-1)).squeeze(-1) * w).sum().backward()
+    fd, vd = F.reshape(n, M * M).to(dev).requires_grad_(), vec.to(dev).requires_grad_()
+    (N().sym_solve(fd, vd) * w.to(dev)).sum().backward()
+    assert torch.allclose(fd.grad.cpu().reshape(n, M, M), fc.grad, rtol=1e-9, atol=1e-11)
+    assert torch.allclose(vd.grad.cpu(), vc.grad, rtol=1e-9, atol=1e-11)
+    with pytest.raises(RuntimeError, match='out='):
+        N().sym_solve(md, vd, out=torch.empty(n, M, dtype=torch.float64, device=dev))
+    with pytest.raises(NotImplementedError):
+        N().sym_invert(md)
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 6])
+def test_eig_sym_backward(dev, n):
+    nb = 30
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(nb, n, n, dtype=torch.float64, generator=g)
+    a = (a + a.transpose(-1, -2)) / 2
+    C = torch.randn(nb, n, n, dtype=torch.float64, generator=g)
+    C = (C + C.transpose(-1, -2)) / 2
+
+    def loss_vals(lam):
+        return (lam.exp() + lam ** 3).sum()       # symmetric in the eigenvalues: order-free
+
+    def loss_full(lam, U):                          # order- and sign-invariant
+        return ((U * torch.tanh(lam).unsqueeze(-2)) @ U.transpose(-1, -2) * C).sum() + loss_vals(lam)
+
+    ac = a.clone().requires_grad_()
+    lam, U = torch.linalg.eigh((ac + ac.transpose(-1, -2)) / 2)
+    loss_vals(lam).backward()
+    g_vals = ac.grad.clone()
+    ac.grad = None
+    lam, U = torch.linalg.eigh((ac + ac.transpose(-1, -2)) / 2)
+    loss_full(lam, U).backward()
+    g_full = ac.grad.clone()
+
+    ad = a.to(dev).requires_grad_()
+    lam_d = N().eig_sym((ad + ad.transpose(-1, -2)) / 2)
+    loss_vals(lam_d).backward()
+    assert torch.allclose(ad.grad.cpu(), g_vals, rtol=1e-8, atol=1e-9)
+    ad.grad = None
+    lam_d, U_d = N().eig_sym((ad + ad.transpose(-1, -2)) / 2, compute_u=True)
+    Cd = C.to(dev)
+    (((U_d * torch.tanh(lam_d).unsqueeze(-2)) @ U_d.transpose(-1, -2) * Cd).sum() + loss_vals(lam_d)).backward()
+    assert torch.allclose(ad.grad.cpu(), g_full, rtol=1e-7, atol=1e-8)
+
+
+def test_reduce_backward(dev):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 33, 7, dtype=torch.float64, generator=g)
+    x[torch.rand(x.shape, generator=g) < 0.1] = float('nan')
+    w = torch.randn(5, 7, dtype=torch.float64, generator=g)
+    R = N().reduce
+    for ours, ref, dim in ((R.nansum, torch.nansum, 1), (R.nanmean, torch.nanmean, 1), (R.nansum, torch.nansum, None),
+                           (R.nanmean, torch.nanmean, (0, 2))):
+        xc = x.clone().requires_grad_()
+        xd = x.to(dev).requires_grad_()
+        if dim is None:
+            (ref(xc) * 3).backward()
+            (ours(xd) * 3).backward()
+        elif dim == 1:
+            (ref(xc, dim=dim) * w).sum().backward()
+            (ours(xd, dim=dim) * w.to(dev)).sum().backward()
+        else:
+            v = torch.arange(33, dtype=torch.float64)
+            (ref(xc, dim=dim) * v).sum().backward()
+            (ours(xd, dim=dim) * v.to(dev)).sum().backward()
+        assert torch.equal(torch.isnan(xd.grad.cpu()), torch.isnan(xc.grad))
+        assert torch.allclose(torch.nan_to_num(xd.grad.cpu()), torch.nan_to_num(xc.grad), rtol=1e-12, atol=1e-14)
+    y = torch.randn(4, 9, dtype=torch.float64, generator=g)
+    yc, yd = y.clone().requires_grad_(), y.to(dev).requires_grad_()
+    (torch.sum(yc, 1) ** 2).sum().backward()
+    (R.sum(yd, 1, keepdim=True) ** 2).sum().backward()
+    assert torch.allclose(yd.grad.cpu(), yc.grad)
+    yc.grad = None; yd.grad = None
+    torch.mean(yc).backward()
+    R.mean(yd).backward()
+    assert torch.allclose(yd.grad.cpu(), yc.grad)
+    with pytest.raises(NotImplementedError):
+        R.nanmax(yd, dim=1)
