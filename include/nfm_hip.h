@@ -168,6 +168,13 @@ int nfm_reduce_all(int dtype, int op, int out_dtype, int64_t n, const void *x, v
 int nfm_reduce_dim(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner,
                    const void *x, void *out, int64_t *idx, void *stream);
 
+/* Same reduction as nfm_reduce_dim (values only) for "few outputs, long reduced axis"
+ * shapes: the reduced axis is cut into `nchunk` ranges reduced in parallel, partials
+ * (nchunk * outer * inner doubles in `workspace`) folded by a second kernel in fixed order. */
+int nfm_reduce_dim_split(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner,
+                         int nchunk, const void *x, void *workspace, size_t workspace_bytes, void *out,
+                         void *stream);
+
 /* One pass over a contiguous (outer, red, inner) view producing, per (outer, inner) entry,
  * four doubles [count, sum(x - K), sum((x - K)^2), K] over the non-NaN elements of the
  * reduced axis (K = a finite element of that slice, chosen by the kernel).  Feeds

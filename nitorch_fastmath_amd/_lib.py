@@ -44,6 +44,7 @@ SIGNATURES = {
     'nfm_batch_matvec': [_i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_reduce_all': [_i, _i, _i, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
     'nfm_reduce_dim': [_i, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    'nfm_reduce_dim_split': [_i, _i, _i, _i64, _i64, _i64, _i, _vp, _vp, ctypes.c_size_t, _vp, _vp],
     'nfm_reduce_moments': [_i, _i64, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
     'nfm_qr_givens': [_i, _i64, _i64, _op, _op, _vp, _vp],
     'nfm_qr_givens_apply': [_i, _i, _i, _i, _i, _i64, _i64, _op, _op, _op, _vp],

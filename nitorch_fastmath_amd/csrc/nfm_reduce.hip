@@ -265,11 +265,42 @@ template <typename T>
 __global__ __launch_bounds__(kRedThreads) void moments_all_k1(const T *__restrict__ x, int64_t n,
                                                                double *__restrict__ partial)
 {
+    using V = typename VecOf<T>::type;
+    constexpr int VEC = VecOf<T>::N;
     __shared__ Mom lds[kRedThreads / kWave];
     const double shift = pick_shift(x, n, 1);
-    Mom m = {0.0, 0.0, 0.0};
+    // same streaming structure as reduce_all_k1: unaligned head, 16-byte vectors, tail
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
+    int64_t head = ((16 - (addr & 15)) & 15) / (int64_t)sizeof(T);
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) / VEC;
+    const int64_t tail0 = head + nvec * VEC;
+    const V *xv = reinterpret_cast<const V *>(x + head);
+    Mom m = {0.0, 0.0, 0.0}, m1 = m, m2 = m, m3 = m;
     const int64_t stride = (int64_t)gridDim.x * kRedThreads;
-    for (int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x; q < n; q += stride) mom_fold(m, x[q], shift);
+    int64_t q = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    for (; q + 3 * stride < nvec; q += 4 * stride) {
+        const V v0 = __builtin_nontemporal_load(xv + q);
+        const V v1 = __builtin_nontemporal_load(xv + q + stride);
+        const V v2 = __builtin_nontemporal_load(xv + q + 2 * stride);
+        const V v3 = __builtin_nontemporal_load(xv + q + 3 * stride);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            mom_fold(m, v0[k], shift);
+            mom_fold(m1, v1[k], shift);
+            mom_fold(m2, v2[k], shift);
+            mom_fold(m3, v3[k], shift);
+        }
+    }
+    for (; q < nvec; q += stride) {
+        const V v0 = xv[q];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) mom_fold(m, v0[k], shift);
+    }
+    const int64_t gid = (int64_t)blockIdx.x * kRedThreads + threadIdx.x;
+    if (gid < head) mom_fold(m1, x[gid], shift);
+    if (gid < n - tail0) mom_fold(m2, x[tail0 + gid], shift);
+    m = mom_merge(mom_merge(m, m1), mom_merge(m2, m3));
     m = mom_wave(m);
     if (threadIdx.x % kWave == 0) lds[threadIdx.x / kWave] = m;
     __syncthreads();
@@ -336,6 +367,85 @@ __global__ __launch_bounds__(256) void moments_dim_k(const T *__restrict__ x, in
         out[4 * e + 2] = m.q;
         out[4 * e + 3] = shift;
     }
+}
+
+// ---- split reduction for "few outputs, long reduced axis" shapes: the reduced axis is cut
+// into nchunk ranges (grid.y), one partial per (chunk, output) in the workspace, then a
+// second tiny kernel folds the chunks in a fixed order (deterministic).
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void reduce_dim_split_k1(const T *__restrict__ x, int64_t outer, int64_t red,
+                                                           int64_t inner, int64_t chunk_len,
+                                                           double *__restrict__ partial)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    const int64_t total = outer * inner;
+    if (e >= total) return;
+    const int64_t o = e / inner, i = e - o * inner;
+    const T *p = x + o * red * inner + i;
+    const int64_t r0 = c * chunk_len;
+    int64_t r1 = r0 + chunk_len;
+    if (r1 > red) r1 = red;
+    double a0 = RedOp<OP>::identity(), a1 = a0;
+    int64_t r = r0;
+    for (; r + 1 < r1; r += 2) {
+        RedOp<OP>::fold(a0, p[r * inner]);
+        RedOp<OP>::fold(a1, p[(r + 1) * inner]);
+    }
+    if (r < r1) RedOp<OP>::fold(a0, p[r * inner]);
+    partial[c * total + e] = RedOp<OP>::merge(a0, a1);
+}
+
+// inner == 1: the lanes of a wave walk one chunk of one row together (coalesced)
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void reduce_row_split_k1(const T *__restrict__ x, int64_t outer, int64_t red,
+                                                           int64_t chunk_len, int nchunk,
+                                                           double *__restrict__ partial)
+{
+    const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) / kWave; // (row, chunk) pair
+    const int lane = threadIdx.x % kWave;
+    if (w >= outer * nchunk) return;
+    const int64_t row = w / nchunk, c = w - row * nchunk;
+    const T *p = x + row * red;
+    const int64_t r0 = c * chunk_len;
+    int64_t r1 = r0 + chunk_len;
+    if (r1 > red) r1 = red;
+    double acc = RedOp<OP>::identity();
+    for (int64_t r = r0 + lane; r < r1; r += kWave) RedOp<OP>::fold(acc, p[r]);
+    acc = wave_reduce<OP>(acc);
+    if (lane == 0) partial[c * outer + row] = acc;
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void reduce_dim_split_k2(const double *__restrict__ partial, int64_t total,
+                                                           int nchunk, void *out, int out_dtype)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    double acc = partial[e];
+    for (int c = 1; c < nchunk; ++c) acc = RedOp<OP>::merge(acc, partial[(int64_t)c * total + e]);
+    if (out_dtype == NFM_F32) static_cast<float *>(out)[e] = (float)acc;
+    else static_cast<double *>(out)[e] = acc;
+}
+
+template <typename T, int OP>
+static int reduce_dim_split_t(int out_dtype, int64_t outer, int64_t red, int64_t inner, int nchunk, const void *x,
+                              double *ws, void *out, hipStream_t s)
+{
+    const T *xp = static_cast<const T *>(x);
+    const int64_t total = outer * inner;
+    const int64_t chunk_len = (red + nchunk - 1) / nchunk;
+    if (inner == 1) {
+        const int64_t nblk = (total * nchunk * kWave + 255) / 256;
+        hipLaunchKernelGGL((reduce_row_split_k1<T, OP>), dim3((unsigned)nblk), dim3(256), 0, s, xp, outer, red,
+                           chunk_len, nchunk, ws);
+    } else {
+        dim3 grid((unsigned)((total + 255) / 256), (unsigned)nchunk, 1);
+        hipLaunchKernelGGL((reduce_dim_split_k1<T, OP>), grid, dim3(256), 0, s, xp, outer, red, inner, chunk_len, ws);
+    }
+    hipLaunchKernelGGL((reduce_dim_split_k2<OP>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, total,
+                       nchunk, out, out_dtype);
+    return launch_status();
 }
 
 template <typename T, int OP>
@@ -419,6 +529,25 @@ int nfm_reduce_dim(int dtype, int op, int out_dtype, int64_t outer, int64_t red,
         NFM_SWITCH_OP(op, return (reduce_dim_t<float, OP>(out_dtype, outer, red, inner, x, out, idx, s)))
     } else {
         NFM_SWITCH_OP(op, return (reduce_dim_t<double, OP>(out_dtype, outer, red, inner, x, out, idx, s)))
+    }
+    return NFM_EINVAL;
+}
+
+int nfm_reduce_dim_split(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner, int nchunk,
+                         const void *x, void *workspace, size_t workspace_bytes, void *out, void *stream)
+{
+    if (dtype != NFM_F32 && dtype != NFM_F64) return NFM_EDTYPE;
+    if (out_dtype != NFM_F32 && out_dtype != NFM_F64) return NFM_EDTYPE;
+    if (outer < 0 || red < 0 || inner < 0 || nchunk < 1 || nchunk > 65535) return NFM_EINVAL;
+    if (outer == 0 || inner == 0) return NFM_OK;
+    if (out == nullptr || workspace == nullptr || (red > 0 && x == nullptr)) return NFM_EINVAL;
+    if (workspace_bytes < (size_t)nchunk * (size_t)(outer * inner) * sizeof(double)) return NFM_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double *ws = static_cast<double *>(workspace);
+    if (dtype == NFM_F32) {
+        NFM_SWITCH_OP(op, return (reduce_dim_split_t<float, OP>(out_dtype, outer, red, inner, nchunk, x, ws, out, s)))
+    } else {
+        NFM_SWITCH_OP(op, return (reduce_dim_split_t<double, OP>(out_dtype, outer, red, inner, nchunk, x, ws, out, s)))
     }
     return NFM_EINVAL;
 }

@@ -86,9 +86,19 @@ def _reduce(op, input, dim, keepdim, out_dtype, want_idx=False):
     idx = torch.empty(subshape, dtype=torch.long, device=dev) if want_idx else None
     if red == 0 and op in (_lib.RED_NANMAX, _lib.RED_NANMIN, _lib.RED_MAX, _lib.RED_MIN):
         raise IndexError('cannot take the max/min over an empty dimension')
-    with torch.cuda.device(dev):
-        _lib.check(L.nfm_reduce_dim(code, op, ocode, outer, red, inner, x.data_ptr(), out.data_ptr(),
-                                    idx.data_ptr() if idx is not None else None, stream_ptr(dev)))
+    nout = outer * inner
+    lanes = nout * (64 if inner == 1 else 1)
+    if idx is None and lanes < (1 << 19) and red >= 4096:
+        # few outputs, long reduced axis: cut the axis so that ~2^20 lanes are busy
+        nchunk = int(builtins.min(65535, builtins.max(2, (1 << 20) // builtins.max(lanes, 1)), red // 256))
+        ws = torch.empty(nchunk * nout, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.nfm_reduce_dim_split(code, op, ocode, outer, red, inner, nchunk, x.data_ptr(), ws.data_ptr(),
+                                              ws.numel() * 8, out.data_ptr(), stream_ptr(dev)))
+    else:
+        with torch.cuda.device(dev):
+            _lib.check(L.nfm_reduce_dim(code, op, ocode, outer, red, inner, x.data_ptr(), out.data_ptr(),
+                                        idx.data_ptr() if idx is not None else None, stream_ptr(dev)))
     if keepdim:
         keptshape = [1 if d in dims else s for d, s in enumerate(shape)]
         out = out.reshape(keptshape)

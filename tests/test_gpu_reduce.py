@@ -177,3 +177,31 @@ def test_large_full_reduction_properties(dev):
     assert float(R().nanmin(x)) == float(torch.nan_to_num(x, nan=float('inf')).min())
     cnt = float(R().nanmean(x, dtype=torch.float64))
     assert abs(cnt - ref / float((~mask).sum())) <= 1e-12
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_skinny_shapes_split_path(dev, dn):
+    """few outputs, long reduced axis: the split kernels (nfm_reduce_dim_split)"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(21)
+    tol = 2e-6 if dn == 'f32' else 1e-12
+    for shape, dim in (((3, 100_003, 2), 1), ((2, 500_001), 1), ((300_007, 3), 0), ((1, 70_000, 1), 1),
+                       ((5, 4096), -1), ((40_000, 2, 2), 0)):
+        x = rng.standard_normal(shape).astype(dtype)
+        x[rng.random(shape) < 0.02] = np.nan
+        xd = t(x, dev)
+        x64 = x.astype(np.float64)
+        r = R().nansum(xd, dim=dim, dtype=torch.float64).cpu().numpy()
+        e = np.nansum(x64, axis=dim)
+        scale = np.nansum(np.abs(x64), axis=dim)
+        assert r.shape == e.shape and (np.abs(r - e) <= 1e-12 * scale).all(), (shape, dim)
+        assert (np.abs(R().nansum(xd, dim=dim).cpu().numpy() - e) <= tol * scale).all()
+        assert np.array_equal(R().nanmax(xd, dim=dim).cpu().numpy(), np.nanmax(x, axis=dim))
+        assert np.array_equal(R().nanmin(xd, dim=dim).cpu().numpy(), np.nanmin(x, axis=dim))
+        m = R().max(xd, dim=dim).cpu().numpy()
+        assert np.array_equal(np.isnan(m), np.isnan(x).any(axis=dim))
+        # indices still come from the one-kernel path
+        v, i = R().nanmax(xd, dim=dim, return_indices=True)
+        assert np.array_equal(i.cpu().numpy(), np.where(np.isnan(x), -np.inf, x).argmax(axis=dim))
+        mm = R().nanmean(xd, dim=dim, dtype=torch.float64).cpu().numpy()
+        assert np.abs(mm - np.nanmean(x64, axis=dim)).max() <= 1e-12 * max(1.0, np.abs(x64[~np.isnan(x64)]).max())
