@@ -2,95 +2,11 @@
 // (reference `_impl/batched.py`).  One matrix per lane; N <= 3 use the reference's
 // adjugate closed forms, 4 <= N <= 8 Gauss-Jordan / LU with partial pivoting in
 // registers, N > 8 the LDS-resident kernels of nfm_big.hpp.
-#include "nfm_record_kernel.hpp"
-#include "nfm_smallmat.hpp"
+#include "nfm_batched_ops.hpp"
 #include "nfm_big.hpp"
+#include "nfm_large.hpp"
 
 namespace nfm {
-
-struct InvParams {
-    int perturb;
-};
-
-template <typename T, int N>
-struct BatchInvOp {
-    using RA = Rec<N, N>;
-    using RB = NoRec;
-    using RC = NoRec;
-    using RO = Rec<N, N>;
-    using Params = InvParams;
-    static constexpr int TILE = pick_tile(RA::C * (int)sizeof(T) + 16);
-    static __device__ __forceinline__ void apply(const T (&a)[RA::Cs], const T (&)[1], const T (&)[1],
-                                                 T (&r)[RO::Cs], const Params &p)
-    {
-        if constexpr (N <= 3) {
-            inv_closed<T, N>(a, r, p.perturb != 0);
-        } else {
-            T f[N][N];
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) f[i][j] = a[i * N + j];
-            gj_inverse<T, N>(f);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) r[i * N + j] = f[i][j];
-        }
-    }
-};
-
-struct NoParamsB {
-    int unused;
-};
-
-template <typename T, int N>
-struct BatchDetOp {
-    using RA = Rec<N, N>;
-    using RB = NoRec;
-    using RC = NoRec;
-    using RO = Rec<1, 1>;
-    using Params = NoParamsB;
-    static constexpr int TILE = pick_tile(RA::C * (int)sizeof(T) + 16);
-    static __device__ __forceinline__ void apply(const T (&a)[RA::Cs], const T (&)[1], const T (&)[1], T (&r)[1],
-                                                 const Params &)
-    {
-        if constexpr (N <= 3) {
-            r[0] = det_closed<T, N>(a);
-        } else {
-            T f[N][N];
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) f[i][j] = a[i * N + j];
-            r[0] = lu_det<T, N>(f);
-        }
-    }
-};
-
-// rows x cols matrix times vector; the reference's closed forms (matvec1/2/3,
-// _impl/batched.py:133-151) are plain sums of products, evaluated left to right
-template <typename T, int R, int C>
-struct BatchMatvecOp {
-    using RA = Rec<R, C>;
-    using RB = Rec<1, C>;
-    using RC = NoRec;
-    using RO = Rec<1, R>;
-    using Params = NoParamsB;
-    static constexpr int TILE = pick_tile((RA::C + C + R) * (int)sizeof(T) + 48);
-    static __device__ __forceinline__ void apply(const T (&a)[RA::Cs], const T (&v)[C], const T (&)[1], T (&y)[R],
-                                                 const Params &)
-    {
-#pragma clang fp contract(off)
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            T s = a[i * C] * v[0];
-#pragma unroll
-            for (int j = 1; j < C; ++j) s = s + a[i * C + j] * v[j];
-            y[i] = s;
-        }
-    }
-};
 
 #define NFM_CASE_N(Nv, ...)   \
     case Nv: {                \
@@ -115,7 +31,13 @@ template <typename T>
 static int batch_inv_t(int N, int flags, int64_t no, int64_t ni, const nfm_operand *a, const nfm_operand *out,
                        void *stream)
 {
-    if (N > 8) return big_batch_inv<T>(N, no, ni, a, out, stream);
+    if (N > 8) {
+        if (no == 1) {
+            const int rc = Large<T>::batch_inv(N, ni, a, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
+        return big_batch_inv<T>(N, no, ni, a, out, stream);
+    }
     InvParams p{(flags & NFM_FLAG_TS_PERTURB) ? 1 : 0};
     NFM_SWITCH_N8(N, return (rec_launch<T, BatchInvOp<T, N>>(a, nullptr, nullptr, out, no, ni, p, stream)))
     return NFM_EINVAL;
@@ -124,7 +46,13 @@ static int batch_inv_t(int N, int flags, int64_t no, int64_t ni, const nfm_opera
 template <typename T>
 static int batch_det_t(int N, int64_t no, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
-    if (N > 8) return big_batch_det<T>(N, no, ni, a, out, stream);
+    if (N > 8) {
+        if (no == 1) {
+            const int rc = Large<T>::batch_det(N, ni, a, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
+        return big_batch_det<T>(N, no, ni, a, out, stream);
+    }
     NoParamsB p{0};
     NFM_SWITCH_N8(N, return (rec_launch<T, BatchDetOp<T, N>>(a, nullptr, nullptr, out, no, ni, p, stream)))
     return NFM_EINVAL;

@@ -286,7 +286,12 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
 
 // Host launcher.  Operands that qualify are tiled; `force_direct` (testing/benchmark
 // knob) sends everything down the per-lane path.
-template <typename T, class Op>
+// FAST_ONLY: instantiate only the compile-time-mode kernel and answer NFM_EFALLBACK when the
+// operands do not qualify (used for orders 9..16, whose run-time-mode twin is not worth its
+// compile time: the caller falls back to the LDS-resident kernels).
+constexpr int NFM_EFALLBACK = -100;
+
+template <typename T, class Op, bool FAST_ONLY = false>
 int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c, const nfm_operand *out,
                int64_t n_outer, int64_t n_inner, const typename Op::Params &prm, void *stream)
 {
@@ -329,17 +334,22 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     if (L::gtotal > 64 * 1024 && !attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
+        if constexpr (!FAST_ONLY)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
         attr_done = true;
     }
-    if (fast)
+    if (fast) {
         hipLaunchKernelGGL((rec_kernel<T, Op, true>), grid, block, (size_t)L::total,
                            static_cast<hipStream_t>(stream), make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc),
                            make_opnd(out, mo), n_inner, prm);
-    else
-        hipLaunchKernelGGL((rec_kernel<T, Op, false>), grid, block, lds, static_cast<hipStream_t>(stream),
-                           make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc), make_opnd(out, mo), n_inner, prm);
+    } else {
+        if constexpr (FAST_ONLY) return NFM_EFALLBACK;
+        else
+            hipLaunchKernelGGL((rec_kernel<T, Op, false>), grid, block, lds, static_cast<hipStream_t>(stream),
+                               make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc), make_opnd(out, mo), n_inner,
+                               prm);
+    }
     return launch_status();
 }
 
