@@ -40,6 +40,9 @@ def parse():
     p.add_argument('--n', type=float, default=None, help='batch per GPU (default: the config size)')
     p.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     p.add_argument('--layout', default='aos', choices=['aos', 'soa'])
+    p.add_argument('--gather', action='store_true',
+                   help='also time the OPTIONAL epilogue: all-gather of the per-rank outputs over xGMI (reported '
+                        'separately as gather_ms; never part of value)')
     return p.parse_args()
 
 
@@ -88,6 +91,7 @@ def make_workload(name, n_arg, device, rank, layout):
         w.desc = f'sym_solve {M}x{M} SPD compact-sym fp32, batch {n:.0e} per GPU, {layout.upper()} layout'
         w.metric, w.unit = f'{M}x{M} compact-sym solves/sec', 'solves/s'
         w.step = lambda: N.sym_solve(mat, vec, out=out)
+        w.output = out
         w.kernel = f'rec_kernel<float, SolveOp<float, {M}, 0>>'
 
         def check():
@@ -263,6 +267,15 @@ def main():
     wall = max_over_ranks(wall, device=device)
     kern_ms = ev0.elapsed_time(ev1) / a.steps          # average launch duration on the stream
     err, exact = w.check()
+    gather_ms = None
+    if a.gather and getattr(w, 'output', None) is not None and world > 1:
+        from nitorch_fastmath_amd.shard import gather_outputs
+        barrier()
+        tg = time.perf_counter()
+        full = gather_outputs(w.output.contiguous(), world * w.output.shape[0])
+        barrier()
+        gather_ms = max_over_ranks(time.perf_counter() - tg, device=device) * 1e3
+        del full
 
     if rank != 0:
         if world > 1:
@@ -289,6 +302,8 @@ def main():
                      'frac_of_achievable_6300': achieved / 6300.0},
         'parity': {'max_rel_err_vs_oracle': err, 'bit_exact_vs_oracle': exact},
     }
+    if gather_ms is not None:
+        line['gather_ms'] = gather_ms   # optional xGMI all-gather of the outputs, outside `value`
     if world == 1 and not a.no_cpu:
         import oracle as O
         O.build()

@@ -9,9 +9,11 @@
 //     loads (1 KiB per wave instruction, the coalescing sweet spot), parks them in
 //     LDS, and each lane then reads its own C-element record with conflict-free
 //     wide LDS reads.  Stores run the same path backwards;
-//   * any other layout (component-major "SoA" fields, broadcast operands,
-//     arbitrary strides) is read/written directly by each lane; for SoA that is
-//     already perfectly coalesced.
+//   * records of exactly 4/8/16 bytes need no transpose (one packed access per lane);
+//   * component-major ("SoA", channel-first) operands stream each component's run with
+//     16-byte loads into an LDS image [component][TILE] (SoaIO);
+//   * anything else (broadcast operands, irregular strides) is read/written element by
+//     element by each lane (rec_direct_load/store in nfm_record_kernel.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -308,49 +310,6 @@ struct SoaIO {
     }
 };
 
-// Direct per-lane access for non-tiled operands (SoA fields, broadcast, strided).
-template <typename T, int C>
-__device__ __forceinline__ void direct_load(const Opnd &op, int64_t o, int64_t i, bool valid, T (&r)[C])
-{
-    const T *p = reinterpret_cast<const T *>(op.ptr) + o * op.so + i * op.si;
-#pragma unroll
-    for (int c = 0; c < C; ++c) r[c] = valid ? p[c * op.sc] : T(1);
-}
-
-template <typename T, int C>
-__device__ __forceinline__ void direct_store(const Opnd &op, int64_t o, int64_t i, bool valid, const T (&r)[C])
-{
-    T *p = reinterpret_cast<T *>(op.ptr) + o * op.so + i * op.si;
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) p[c * op.sc] = r[c];
-    }
-}
-
-// Full (R x Cc) matrix, direct access with row/col strides.
-template <typename T, int R, int Cc>
-__device__ __forceinline__ void direct_load_mat(const Opnd &op, int64_t o, int64_t i, bool valid, T (&r)[R * Cc])
-{
-    const T *p = reinterpret_cast<const T *>(op.ptr) + o * op.so + i * op.si;
-#pragma unroll
-    for (int a = 0; a < R; ++a)
-#pragma unroll
-        for (int b = 0; b < Cc; ++b) r[a * Cc + b] = valid ? p[a * op.sr + b * op.sc] : T(a == b ? 1 : 0);
-}
-
-template <typename T, int R, int Cc>
-__device__ __forceinline__ void direct_store_mat(const Opnd &op, int64_t o, int64_t i, bool valid,
-                                                 const T (&r)[R * Cc])
-{
-    T *p = reinterpret_cast<T *>(op.ptr) + o * op.so + i * op.si;
-    if (valid) {
-#pragma unroll
-        for (int a = 0; a < R; ++a)
-#pragma unroll
-            for (int b = 0; b < Cc; ++b) p[a * op.sr + b * op.sc] = r[a * Cc + b];
-    }
-}
-
 // ------------------------------------------------------------------ host side
 // Can the operand take the LDS-transposed path?  It must be a single contiguous
 // batch-major block: records of C elements back to back, 16-byte aligned base.
@@ -359,8 +318,7 @@ inline bool tile_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_
 {
     if (op->ptr == nullptr) return false;
     if (reinterpret_cast<uintptr_t>(op->ptr) % 16 != 0) return false;
-    if (n_outer != 1 && op->stride_outer != n_inner * (int64_t)C) return false;
-    if (n_outer != 1) return false; // facade collapses contiguous outer levels
+    if (n_outer != 1) return false; // the facade collapses contiguous outer levels into one
     if (op->stride_inner != C) return false;
     if (rows > 1) {
         if (op->stride_row != cols || op->stride_col != 1) return false;

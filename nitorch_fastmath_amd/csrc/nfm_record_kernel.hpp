@@ -1,10 +1,11 @@
 // nfm_record_kernel.hpp -- the one kernel skeleton every lane-per-matrix op uses.
 //
-//   rec_kernel<T, Op>: up to three input records (A, B, C) and one output record
+//   rec_kernel<T, Op, FAST>: up to three input records (A, B, C) and one output record
 //   per batch element; Op::apply() is the in-register arithmetic.  Each operand
-//   independently takes the LDS-transposed path (contiguous batch-major storage)
-//   or the direct per-lane path (SoA / broadcast / strided); the choice is a
-//   wave-uniform kernel argument, so there is no divergence.
+//   independently takes one of four movement modes (LDS-transposed AoS tile, packed
+//   per-lane access, LDS component-major tile, strided per-lane access); the choice is a
+//   wave-uniform kernel argument (or a compile-time constant in the FAST kernel), so
+//   there is no divergence.
 //
 // Timeline of a workgroup (TILE lanes = TILE batch elements):
 //   1. issue every 16-byte global load of the tile for all tiled inputs (no waits
@@ -284,8 +285,7 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     rec_direct_store<T, RO>(out, o, i, valid, ro);
 }
 
-// Host launcher.  Operands that qualify are tiled; `force_direct` (testing/benchmark
-// knob) sends everything down the per-lane path.
+// Host launcher: picks the movement mode of every operand and the kernel variant.
 // FAST_ONLY: instantiate only the compile-time-mode kernel and answer NFM_EFALLBACK when the
 // operands do not qualify (used for orders 9..16, whose run-time-mode twin is not worth its
 // compile time: the caller falls back to the LDS-resident kernels).

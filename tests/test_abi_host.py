@@ -61,6 +61,16 @@ def test_argument_validation_without_gpu(L):
     # empty batches succeed without a launch
     assert L.nfm_sym_solve(0, 4, 0, 1, 0, r, r, r, None, None) == 0
     assert L.nfm_sym_invert(1, 3, 0, 0, 0, r, r, None) == 0
+    # qr family: order / side / index checks happen before any launch
+    assert L.nfm_qr_eig_sym(0, 17, 1, 0, 10, 1e-32, 1, 1, r, 8, None) == -3
+    assert L.nfm_qr_eig_sym(0, 3, 1, 0, -1, 1e-32, 1, 1, r, 8, None) == -1
+    assert L.nfm_qr_givens_apply(0, 3, 5, 0, 1, 1, 1, r, r, r, None) == -1     # bad side
+    assert L.nfm_qr_givens_apply(0, 3, 0, 0, 3, 1, 1, r, r, r, None) == -1     # j out of range
+    assert L.nfm_qr_householder(1, 4, 4, 1, 1, r, 8, None) == -1               # basis out of range
+    assert L.nfm_qr_householder_apply(1, 4, 5, 0, 1, 1, r, r, None) == -1      # reflector longer than n
+    assert L.nfm_qr_hessenberg(0, 3, 0, 1, 0, 1, 0, r, None, None) == 0        # empty batch
+    assert L.nfm_reduce_dim_split(0, 0, 0, 1, 10, 1, 0, None, 8, 64, 8, None) == -1
+    assert L.nfm_reduce_moments(3, 1, 1, 1, None, None, 0, None, None) == -2
     bad = Operand(6, 0, 0, 0, 1)   # misaligned for float
     assert L.nfm_sym_det(0, 3, 1, 1, ctypes.byref(bad), ctypes.byref(bad), None) == -4
 
@@ -73,6 +83,10 @@ def test_facade_refuses_cpu_tensors_and_bad_dtypes():
         N.batchinv(torch.eye(3)[None])
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         N.reduce.nansum(torch.ones(4))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        N.eig_sym(torch.eye(3)[None])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        N.qr.givens(torch.ones(3), torch.ones(3))
 
 
 def test_product_never_imports_oracle():
