@@ -38,6 +38,50 @@ struct BatchInvOp {
     }
 };
 
+// Inverse built column by column (LU once, N unit-vector solves), each column written
+// straight into the lane's slot of the LDS output image: N^2 + 3N live values.  Used for
+// the orders where the in-place Gauss-Jordan no longer fits the register file.
+// SYM: compact symmetric in and out (sym_invert); else full N x N (batchinv).
+template <typename T, int N, bool SYM>
+struct InvStreamOp {
+    using RA = Rec<(SYM ? 1 : N), (SYM ? sym_k(N) : N)>;
+    using RB = NoRec;
+    using RC = NoRec;
+    using RO = RA;
+    using Params = InvParams;
+    static constexpr bool kStream = true;
+    static constexpr int TILE = 64;
+    static __device__ __forceinline__ void apply(const T (&)[RA::Cs], const T (&)[1], const T (&)[1], T (&)[RO::Cs],
+                                                 const Params &)
+    {
+    }
+    static __device__ __forceinline__ void apply_stream(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
+                                                        T *own, const Params &)
+    {
+        T a[N][N];
+        int rowid[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) a[i][j] = SYM ? r[sym_idx(N, i, j)] : r[i * N + j];
+        lu_factor_rowid<T, N>(a, rowid);
+        // a real loop: unrolled, the scheduler interleaves several columns' substitutions
+        // and the live ranges of their x[] vectors push the kernel into scratch
+#pragma unroll 1
+        for (int c = 0; c < N; ++c) {
+            T x[N];
+            lu_solve_unit<T, N>(a, rowid, c, x);
+            if constexpr (SYM) { // entry (c, j >= c) comes from column c, like the reference
+#pragma unroll
+                for (int j = c; j < N; ++j) own[sym_idx(N, c, j)] = x[j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) own[i * N + c] = x[i];
+            }
+        }
+    }
+};
+
 struct NoParamsB {
     int unused;
 };

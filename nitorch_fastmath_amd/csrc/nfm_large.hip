@@ -16,46 +16,30 @@ namespace nfm {
         constexpr int N = Nv; \
         __VA_ARGS__;          \
     } break;
-#define NFM_LSWITCH12(Nexpr, ...)   \
-    switch (Nexpr) {               \
-        NFM_LCASE(9, __VA_ARGS__)  \
-        NFM_LCASE(10, __VA_ARGS__) \
-        NFM_LCASE(11, __VA_ARGS__) \
-        NFM_LCASE(12, __VA_ARGS__) \
-    default:                       \
-        break;                     \
-    }
-#define NFM_LSWITCH13(Nexpr, ...)  \
-    switch (Nexpr) {               \
-        NFM_LCASE(9, __VA_ARGS__)  \
-        NFM_LCASE(10, __VA_ARGS__) \
-        NFM_LCASE(11, __VA_ARGS__) \
-        NFM_LCASE(12, __VA_ARGS__) \
-        NFM_LCASE(13, __VA_ARGS__) \
-    default:                       \
-        break;                     \
-    }
-#define NFM_LSWITCH16(Nexpr, ...)  \
-    switch (Nexpr) {               \
-        NFM_LCASE(9, __VA_ARGS__)  \
-        NFM_LCASE(10, __VA_ARGS__) \
-        NFM_LCASE(11, __VA_ARGS__) \
-        NFM_LCASE(12, __VA_ARGS__) \
-        NFM_LCASE(13, __VA_ARGS__) \
-        NFM_LCASE(14, __VA_ARGS__) \
-        NFM_LCASE(15, __VA_ARGS__) \
-        NFM_LCASE(16, __VA_ARGS__) \
-    default:                       \
-        break;                     \
-    }
-// The in-place Gauss-Jordan ops keep N^2 values live plus the select network's temporaries:
-// measured on MI355X they stay in registers up to 13 (f32) / 12 (f64); beyond that the
-// spills make them slower than the LDS-resident kernels, which take over.
-#if NFM_LARGE_PART % 2 == 0
-#define NFM_LSWITCH_GJ NFM_LSWITCH13
-#else
-#define NFM_LSWITCH_GJ NFM_LSWITCH12
-#endif
+#define NFM_LC4(a, b, c, d, ...) NFM_LCASE(a, __VA_ARGS__) NFM_LCASE(b, __VA_ARGS__) NFM_LCASE(c, __VA_ARGS__) NFM_LCASE(d, __VA_ARGS__)
+#define NFM_LSWITCH_9_12(Nexpr, ...) \
+    switch (Nexpr) { NFM_LC4(9, 10, 11, 12, __VA_ARGS__) default: break; }
+#define NFM_LSWITCH_9_13(Nexpr, ...) \
+    switch (Nexpr) { NFM_LC4(9, 10, 11, 12, __VA_ARGS__) NFM_LCASE(13, __VA_ARGS__) default: break; }
+#define NFM_LSWITCH_9_14(Nexpr, ...) \
+    switch (Nexpr) { NFM_LC4(9, 10, 11, 12, __VA_ARGS__) NFM_LCASE(13, __VA_ARGS__) NFM_LCASE(14, __VA_ARGS__) default: break; }
+#define NFM_LSWITCH_14_16(Nexpr, ...) \
+    switch (Nexpr) { NFM_LCASE(14, __VA_ARGS__) NFM_LCASE(15, __VA_ARGS__) NFM_LCASE(16, __VA_ARGS__) default: break; }
+#define NFM_LSWITCH16(Nexpr, ...) \
+    switch (Nexpr) { NFM_LC4(9, 10, 11, 12, __VA_ARGS__) NFM_LC4(13, 14, 15, 16, __VA_ARGS__) default: break; }
+
+// Coverage is set by what stays in registers (checked with -Rpass-analysis=kernel-resource-usage
+// and timed on MI355X, profiles/r01c): beyond these ranges the spills make the register kernels
+// slower than the LDS-resident ones, which take over.
+//   inverse, compact symmetric : column-by-column LU (InvStreamOp)     f32 9..12, f64 9..14
+//   inverse, general           : in-place Gauss-Jordan (BatchInvOp)    f32 9..13, f64 9..13
+//   determinant, general       : LU (BatchDetOp)                       f32 9..16, f64 9..14
+// NB (toolchain): with hipcc 7.2 the f32 column-by-column inverse gives WRONG, run-to-run
+// varying results for N >= 13 (the f64 instantiation of the same source is correct; the
+// kernels are far beyond 256 live registers and the symptom is that of a spill placed under
+// a partial EXEC mask).  scripts/dbg_stream.hip reproduces it stand-alone.  Those orders
+// therefore stay on the LDS-resident kernels, and tests/test_gpu_large_orders.py checks
+// every order 9..16 of every op against the oracle on thousands of matrices.
 
 #if NFM_LARGE_PART == 0 || NFM_LARGE_PART == 1
 #if NFM_LARGE_PART == 0
@@ -97,8 +81,12 @@ using TI = double;
 #endif
 static int large_sym_invert_impl(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream)
 {
-    NoParams p{0};
-    NFM_LSWITCH_GJ(M, return (rec_launch<TI, InvertOp<TI, N, false>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
+    InvParams p{0};
+#if NFM_LARGE_PART == 2
+    NFM_LSWITCH_9_12(M, return (rec_launch<TI, InvStreamOp<TI, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
+#else
+    NFM_LSWITCH_9_14(M, return (rec_launch<TI, InvStreamOp<TI, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
+#endif
     return NFM_EFALLBACK;
 }
 #if NFM_LARGE_PART == 2
@@ -117,7 +105,8 @@ using TB = double;
 static int large_batch_inv_impl(int N_, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
     InvParams p{0};
-    NFM_LSWITCH_GJ(N_, return (rec_launch<TB, BatchInvOp<TB, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH_9_13(N_, return (rec_launch<TB, BatchInvOp<TB, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+
     return NFM_EFALLBACK;
 }
 #if NFM_LARGE_PART == 4
@@ -143,7 +132,11 @@ static int large_sym_matvec_impl(int M, int mode, int64_t ni, const nfm_operand 
 static int large_batch_det_impl(int N_, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
     NoParamsB p{0};
-    NFM_LSWITCH_GJ(N_, return (rec_launch<TM, BatchDetOp<TM, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+    #if NFM_LARGE_PART == 6
+    NFM_LSWITCH16(N_, return (rec_launch<TM, BatchDetOp<TM, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+#else
+    NFM_LSWITCH_9_14(N_, return (rec_launch<TM, BatchDetOp<TM, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+#endif
     return NFM_EFALLBACK;
 }
 #if NFM_LARGE_PART == 6

@@ -2,9 +2,10 @@
 // only in their contiguous-operand FAST form).  Each function answers NFM_EFALLBACK when
 // the order / dtype / layout is not covered; the caller then uses the LDS-resident kernels
 // of nfm_big.hpp.  Coverage is set by the 512-register budget of a lane:
-//   sym_solve, sym_det            : f32 9..16, f64 9..16 (f64 15-16 spill a little)
-//   sym_matvec (+add/sub)         : f32 9..16, f64 9..16
-//   sym_invert (full), batch_inv, batch_det : f32 9..13, f64 9..12 (in-place Gauss-Jordan)
+//   sym_solve, sym_det, sym_matvec : f32 9..16, f64 9..16 (f64 solve 15-16 spills a little)
+//   sym_invert (full)              : f32 9..12, f64 9..14   (LU + column-by-column solves)
+//   batch_inv                      : f32 9..13, f64 9..13   (in-place Gauss-Jordan)
+//   batch_det                      : f32 9..16, f64 9..14
 #pragma once
 #include "nfm_common.hpp"
 

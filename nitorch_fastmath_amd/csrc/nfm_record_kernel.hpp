@@ -16,6 +16,7 @@
 //   5. the output goes back through LDS (barrier) and out with 16-byte stores, or
 //      directly when it is not batch-major contiguous.
 #pragma once
+#include <type_traits>
 #include "nfm_common.hpp"
 
 namespace nfm {
@@ -148,6 +149,12 @@ __device__ __forceinline__ void rec_direct_store(const Opnd &op, int64_t o, int6
     }
 }
 
+// Ops that define `static constexpr bool kStream = true` provide apply_stream() (see step 4)
+template <class Op, class = void>
+struct op_streams : std::false_type {};
+template <class Op>
+struct op_streams<Op, std::void_t<decltype(Op::kStream)>> : std::bool_constant<Op::kStream> {};
+
 // FAST = every operand is a contiguous batch-major block (the default torch layout):
 // the movement mode of each operand is then a compile-time constant (packed access for
 // 4/8/16-byte records, LDS transpose for the rest), which removes every mode branch and
@@ -256,8 +263,18 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     if constexpr (!FAST && IC::can_soa)
         if (sC) IC::SO::read_own(smem + oC, rc);
 
-    // 4. arithmetic
-    Op::apply(ra, rb, rc, ro, prm);
+    // 4. arithmetic.  Streaming Ops (FAST kernel, tiled output) write their output record
+    //    element by element into this lane's slot of the LDS image instead of returning
+    //    it in registers (an inverse built column by column never holds two matrices).
+    if constexpr (op_streams<Op>::value && FAST && IO_::can_tile) {
+        T *own = reinterpret_cast<T *>(smem + oO + threadIdx.x * IO_::IO::kRowStride);
+        Op::apply_stream(ra, rb, rc, own, prm);
+        __syncthreads();
+        IO_::IO::flush(reinterpret_cast<T *>(out.ptr) + tile0 * RO::C, left * RO::C, smem + oO);
+        return;
+    } else {
+        Op::apply(ra, rb, rc, ro, prm);
+    }
 
     // 5. output
     if constexpr (IO_::can_tile) {

@@ -316,6 +316,7 @@ __device__ __forceinline__ void gj_inverse(T (&a)[N][N])
                 for (int j = 0; j < N; ++j) a[i][j] -= f * a[k][j];
             }
         }
+        if constexpr (N > 8) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int k = N - 2; k >= 0; --k) {
@@ -329,6 +330,80 @@ __device__ __forceinline__ void gj_inverse(T (&a)[N][N])
                 a[i][c] = s ? t : a[i][c];
             }
         }
+        if constexpr (N > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// LU factorisation in place with partial pivoting, keeping the row permutation as the
+// original index of every row (rowid), and the solve of L U x = P e_c for one unit vector.
+// Together they build an inverse column by column with only N^2 + 3N live values -- the
+// in-place Gauss-Jordan needs noticeably more temporaries and spills beyond 13x13.
+template <typename T, int N>
+__device__ __forceinline__ void lu_factor_rowid(T (&a)[N][N], int (&rowid)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) rowid[i] = i;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if constexpr (N > 1) {
+            int p = k;
+            T best = fabs_(a[k][k]);
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const T x = fabs_(a[i][k]);
+                const bool g = x > best;
+                best = g ? x : best;
+                p = g ? i : p;
+            }
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const bool s = (p == i);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const T t = a[k][j];
+                    a[k][j] = s ? a[i][j] : t;
+                    a[i][j] = s ? t : a[i][j];
+                }
+                const int ti = rowid[k];
+                rowid[k] = s ? rowid[i] : ti;
+                rowid[i] = s ? ti : rowid[i];
+            }
+        }
+        const T rp = T(1) / a[k][k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const T l = a[i][k] * rp;
+            a[i][k] = l;
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) a[i][j] -= l * a[k][j];
+        }
+        // keep the scheduler from interleaving elimination steps: it lengthens live ranges
+        // until a 16x16 matrix no longer fits the register file
+        if constexpr (N > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// x = A^-1 e_c from the factors above (column c of the inverse)
+template <typename T, int N>
+__device__ __forceinline__ void lu_solve_unit(const T (&lu)[N][N], const int (&rowid)[N], int c, T (&x)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = (rowid[i] == c) ? T(1) : T(0);
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        T s = x[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s -= lu[i][j] * x[j];
+        x[i] = s;
+        if constexpr (N > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        T s = x[i];
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) s -= lu[i][j] * x[j];
+        x[i] = s / lu[i][i];
+        if constexpr (N > 8) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -370,6 +445,7 @@ __device__ __forceinline__ T lu_det(T (&a)[N][N])
 #pragma unroll
             for (int j = k + 1; j < N; ++j) a[i][j] -= l * a[k][j];
         }
+        if constexpr (N > 8) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) det *= a[k][k];
