@@ -39,7 +39,7 @@ namespace nfm {
 // kernels are far beyond 256 live registers and the symptom is that of a spill placed under
 // a partial EXEC mask).  scripts/dbg_stream.hip reproduces it stand-alone.  Those orders
 // therefore stay on the LDS-resident kernels, and tests/test_gpu_large_orders.py checks
-// every order 9..16 of every op against the oracle on thousands of matrices.
+// every order 9..16 of every op against the CPU restatement on thousands of matrices.
 
 #if NFM_LARGE_PART == 0 || NFM_LARGE_PART == 1
 #if NFM_LARGE_PART == 0

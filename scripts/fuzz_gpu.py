@@ -70,7 +70,7 @@ while time.time() < t_end:
     dtype = [np.float32, np.float64][rng.integers(0, 2)]
     M = int(rng.integers(1, 17))
     op = ['solve', 'matvec', 'addmatvec', 'invert', 'invert_diag', 'det', 'batchinv', 'batchdet', 'batchmatvec', 'nansum',
-          'nanmax', 'outer', 'to_full', 'eig'][rng.integers(0, 14)]
+          'nanmax', 'outer', 'to_full', 'eig', 'solve_inplace_eps', 'qr_misc', 'matmul'][rng.integers(0, 17)]
     batch = rand_batch()
     tol = TOL[dtype]
     try:
@@ -87,6 +87,51 @@ while time.time() < t_end:
             else:
                 inp = rng.standard_normal(batch + (M,)).astype(dtype)
                 got, ref, tol = N.sym_addmatvec(relayout(T(inp), 1), md, vd), O.sym_matvec(mat, vec, inp, 1), 0.0
+        elif op == 'solve_inplace_eps':
+            mat, vec = spd(batch, M, dtype), rng.standard_normal(batch + (M,)).astype(dtype)
+            eps = [float(e) for e in rng.random(int(rng.integers(1, M + 1)))]
+            e = np.array((eps + [eps[-1]] * M)[:M], dtype)
+            mat_e = mat.copy()
+            mat_e[..., :M] += e
+            vd = relayout(T(vec), 1)
+            r = N.sym_solve_(relayout(T(mat), 1), vd, eps=eps)
+            assert r.data_ptr() == vd.data_ptr()
+            got, ref = vd, O.sym_solve(mat_e, vec)
+        elif op == 'matmul':
+            k, d = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+            j = rng.standard_normal(batch + (k, d)).astype(dtype)
+            h = spd(batch, k, dtype)
+            got, ref, tol = N.sym_matmul(relayout(T(j), 2), relayout(T(h), 1)), O.sym_matmul(j, h), 0.0
+        elif op == 'qr_misc':
+            Mq = int(rng.integers(1, 17))
+            a = rng.standard_normal(batch + (Mq, Mq)).astype(dtype)
+            qtol = tol * max(1.0, Mq * Mq / 4.0) * 4
+            which = rng.integers(0, 4)
+            ad = relayout(T(a), 2)
+            if which == 0:
+                got, ref, tol = N.qr.hessenberg(ad), O.hessenberg(a), qtol
+            elif which == 1:
+                hz = np.triu(a, -1)
+                q, r = N.qr.qr_hessenberg(relayout(T(hz), 2))
+                qo, ro = O.qr_hessenberg(hz)
+                got, ref, tol = torch.stack([q, r]), np.stack([qo, ro]), qtol
+            elif which == 2:
+                got, ref, tol = N.qr.hessenberg_sym(ad, upper=bool(rng.integers(0, 2))), None, qtol
+                # recompute with the same `upper` is awkward to thread through: compare eigen-invariants
+                s_in = np.triu(a) + np.swapaxes(np.triu(a, 1), -1, -2)
+                g = got.cpu().numpy().astype(np.float64)
+                ok1 = np.abs(np.trace(g, axis1=-2, axis2=-1) - np.trace(a, axis1=-2, axis2=-1)).max() <= 50 * qtol * max(1.0, np.abs(a).max()) * Mq
+                count += 1
+                if not ok1 or not np.allclose(g, np.swapaxes(g, -1, -2)):
+                    fails += 1
+                    print('FAIL hessenberg_sym trace/symmetry', dtype.__name__, Mq, batch)
+                continue
+            else:
+                v = rng.standard_normal(batch + (Mq,)).astype(dtype)
+                b = int(rng.integers(0, Mq))
+                u, al = N.qr.householder(relayout(T(v), 1), basis=b, return_alpha=True)
+                uo, alo = O.householder(v, b)
+                got, ref, tol = torch.cat([u, al.unsqueeze(-1)], -1), np.concatenate([uo, alo[..., None]], -1), qtol
         elif op in ('invert', 'invert_diag', 'det', 'to_full'):
             mat = spd(batch, M, dtype)
             md = relayout(T(mat), 1)

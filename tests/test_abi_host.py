@@ -162,3 +162,60 @@ def test_mat_kind_and_utils():
     assert utils.eps(torch.float32) == 2 ** -23 and utils.eps('float64') == 2 ** -52
     x = torch.zeros(3, 6)
     assert sym.sym_diag(x).shape == (3, 3) and sym.sym_diag(x).data_ptr() == x.data_ptr()
+
+
+def test_compat_package_resolves_reference_import_paths():
+    """`import nitorch_fastmath` + the reference's module paths, served by the backend"""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'compat'))
+    try:
+        sys.modules.pop('nitorch_fastmath', None)
+        nf = importlib.import_module('nitorch_fastmath')
+        from nitorch_fastmath.sym import sym_solve, sym_invert, sym_matvec, sym_addmatvec_, sym_solve_  # noqa: F401
+        from nitorch_fastmath.batched import batchinv, batchdet, batchmatvec  # noqa: F401
+        from nitorch_fastmath.qr import eig_sym, givens, householder  # noqa: F401
+        from nitorch_fastmath.reduce import nansum, nanmax, nanmean  # noqa: F401
+        import nitorch_fastmath_amd as N
+        assert nf.sym_solve is N.sym.sym_solve and nf.reduce is N.reduce
+        # every public name of the reference's hot-path modules exists
+        for name in ['sym_to_full', 'sym_diag', 'sym_outer', 'sym_det', 'sym_matmul', 'sym_matvec', 'sym_addmatvec',
+                     'sym_addmatvec_', 'sym_submatvec', 'sym_submatvec_', 'sym_solve', 'sym_solve_', 'sym_invert',
+                     'sym_invert_']:
+            assert callable(getattr(nf.sym, name)), name
+        for name in ['eig_sym', 'qr_hessenberg', 'rq_hessenberg', 'hessenberg', 'hessenberg_sym', 'householder',
+                     'householder_apply', 'givens', 'givens_apply']:
+            assert callable(getattr(nf.qr, name)), name
+        for name in ['min', 'max', 'nanmin', 'nanmax', 'median', 'sum', 'nansum', 'mean', 'nanmean', 'var', 'nanvar',
+                     'std', 'nanstd']:
+            assert callable(getattr(nf.reduce, name)), name
+    finally:
+        sys.path.remove(os.path.join(ROOT, 'compat'))
+        for k in [k for k in sys.modules if k == 'nitorch_fastmath' or k.startswith('nitorch_fastmath.')]:
+            sys.modules.pop(k)
+
+
+def test_signatures_match_the_reference():
+    """argument names and order of the public functions (reference file:line in the docstrings)"""
+    import inspect
+    import nitorch_fastmath_amd as N
+
+    def names(fn):
+        return list(inspect.signature(fn).parameters)
+    assert names(N.sym.sym_solve)[:3] == ['mat', 'vec', 'eps']                 # _impl/sym.py:327
+    assert names(N.sym.sym_invert)[:2] == ['mat', 'diag']                       # _impl/sym.py:455
+    assert names(N.sym.sym_matvec)[:2] == ['mat', 'vec']                        # _impl/sym.py:134
+    assert names(N.batched.batchinv)[0] == 'a' and names(N.batched.batchmatvec) == ['mat', 'vec']
+    assert names(N.qr.eig_sym) == ['a', 'compute_u', 'upper', 'inplace', 'check_finite', 'max_iter', 'tol']   # qr.py:30-38
+    assert names(N.qr.hessenberg_sym) == ['a', 'upper', 'fill', 'inplace', 'check_finite', 'compute_u']        # qr.py:226-233
+    assert names(N.qr.householder) == ['x', 'basis', 'inplace', 'check_finite', 'return_alpha']               # qr.py:278-284
+    assert names(N.qr.householder_apply) == ['a', 'u', 'k', 'side', 'inverse', 'inplace', 'check_finite']     # qr.py:330-338
+    assert names(N.qr.givens_apply) == ['a', 'c', 's', 'i', 'j', 'side', 'inplace', 'check_finite']           # qr.py:375-384
+    assert names(N.qr.rq_hessenberg) == ['h', 'u', 'inplace', 'check_finite']                                 # qr.py:103-108
+    red = ['input', 'dim', 'keepdim', 'omitnan', 'inplace']
+    assert names(N.reduce.max) == red + ['return_indices', 'out']                                              # reduce.py:145-153
+    assert names(N.reduce.nanmax) == ['input', 'dim', 'keepdim', 'inplace', 'return_indices', 'out']          # reduce.py:267-274
+    assert names(N.reduce.sum) == red + ['dtype', 'out']                                                       # reduce.py:431-439
+    assert names(N.reduce.nansum) == ['input', 'dim', 'keepdim', 'inplace', 'dtype', 'out']                   # reduce.py:471-478
+    assert names(N.reduce.var) == ['input', 'dim', 'keepdim', 'unbiased', 'omitnan', 'inplace', 'dtype', 'out']  # reduce.py:597-606
+    assert names(N.reduce.nanstd) == ['input', 'dim', 'keepdim', 'unbiased', 'inplace', 'dtype', 'out']       # reduce.py:729-737
