@@ -1,0 +1,43 @@
+"""bench.py prints ONE JSON line with the driver's contract fields plus roofline / cpu_baseline."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args):
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().split('\n') if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_default_workload_contract(dev):
+    d = run_bench('--gpus', '1', '--steps', '3', '--warmup', '1', '--n', '2e6')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
+    assert 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['bytes_per_unit'] == 72
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit']
+    assert d['parity']['bit_exact_vs_oracle'] is True
+    assert abs(d['value'] - 2e6 * 3 / (d['ms_per_step'] * 3e-3)) / d['value'] < 1e-6
+
+
+def test_other_workloads_run(dev):
+    for w, n in (('sym_solve6', '1e6'), ('batchinv8', '2e5'), ('nansum', '4e7'), ('sym_invert3', '1e5')):
+        d = run_bench('--workload', w, '--steps', '2', '--warmup', '1', '--n', n, '--no-cpu')
+        assert d['value'] > 0 and 'cpu_baseline' not in d and d['roofline']['achieved'] > 0
