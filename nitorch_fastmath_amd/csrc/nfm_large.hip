@@ -28,18 +28,14 @@ namespace nfm {
 #define NFM_LSWITCH16(Nexpr, ...) \
     switch (Nexpr) { NFM_LC4(9, 10, 11, 12, __VA_ARGS__) NFM_LC4(13, 14, 15, 16, __VA_ARGS__) default: break; }
 
-// Coverage is set by what stays in registers (checked with -Rpass-analysis=kernel-resource-usage
-// and timed on MI355X, profiles/r01c): beyond these ranges the spills make the register kernels
-// slower than the LDS-resident ones, which take over.
-//   inverse, compact symmetric : column-by-column LU (InvStreamOp)     f32 9..12, f64 9..14
-//   inverse, general           : in-place Gauss-Jordan (BatchInvOp)    f32 9..13, f64 9..13
-//   determinant, general       : LU (BatchDetOp)                       f32 9..16, f64 9..14
-// NB (toolchain): with hipcc 7.2 the f32 column-by-column inverse gives WRONG, run-to-run
-// varying results for N >= 13 (the f64 instantiation of the same source is correct; the
-// kernels are far beyond 256 live registers and the symptom is that of a spill placed under
-// a partial EXEC mask).  scripts/dbg_stream.hip reproduces it stand-alone.  Those orders
-// therefore stay on the LDS-resident kernels, and tests/test_gpu_large_orders.py checks
-// every order 9..16 of every op against the CPU restatement on thousands of matrices.
+// Every op covers orders 9..16 in both dtypes.  The pivoting code uses OPAQUE selects here
+// (Sel<true>, nfm_smallmat.hpp): no data-dependent control flow is left, so whatever spill
+// code the big eliminations need runs under a full EXEC mask, and most kernels need none
+// (-Rpass-analysis=kernel-resource-usage: every f32 kernel and f64 up to 13 are spill-free).
+//   inverse (compact symmetric and general): LU + column-by-column unit solves (InvStreamOp)
+//   solve / determinants: Gaussian elimination with partial pivoting (SolveOp, DetOp, BatchDetOp)
+// tests/test_gpu_large_orders.py checks every order of every op against the CPU restatement
+// on thousands of matrices, twice.
 
 #if NFM_LARGE_PART == 0 || NFM_LARGE_PART == 1
 #if NFM_LARGE_PART == 0
@@ -83,9 +79,9 @@ static int large_sym_invert_impl(int M, int64_t ni, const nfm_operand *mat, cons
 {
     InvParams p{0};
 #if NFM_LARGE_PART == 2
-    NFM_LSWITCH_9_12(M, return (rec_launch<TI, InvStreamOp<TI, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(M, return (rec_launch<TI, InvStreamOp<TI, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
 #else
-    NFM_LSWITCH_9_14(M, return (rec_launch<TI, InvStreamOp<TI, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(M, return (rec_launch<TI, InvStreamOp<TI, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
 #endif
     return NFM_EFALLBACK;
 }
@@ -105,7 +101,7 @@ using TB = double;
 static int large_batch_inv_impl(int N_, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
     InvParams p{0};
-    NFM_LSWITCH_9_13(N_, return (rec_launch<TB, BatchInvOp<TB, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(N_, return (rec_launch<TB, InvStreamOp<TB, N, false>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
 
     return NFM_EFALLBACK;
 }
@@ -135,7 +131,7 @@ static int large_batch_det_impl(int N_, int64_t ni, const nfm_operand *a, const 
     #if NFM_LARGE_PART == 6
     NFM_LSWITCH16(N_, return (rec_launch<TM, BatchDetOp<TM, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
 #else
-    NFM_LSWITCH_9_14(N_, return (rec_launch<TM, BatchDetOp<TM, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(N_, return (rec_launch<TM, BatchDetOp<TM, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
 #endif
     return NFM_EFALLBACK;
 }

@@ -2,10 +2,7 @@
 // only in their contiguous-operand FAST form).  Each function answers NFM_EFALLBACK when
 // the order / dtype / layout is not covered; the caller then uses the LDS-resident kernels
 // of nfm_big.hpp.  Coverage is set by the 512-register budget of a lane:
-//   sym_solve, sym_det, sym_matvec : f32 9..16, f64 9..16 (f64 solve 15-16 spills a little)
-//   sym_invert (full)              : f32 9..12, f64 9..14   (LU + column-by-column solves)
-//   batch_inv                      : f32 9..13, f64 9..13   (in-place Gauss-Jordan)
-//   batch_det                      : f32 9..16, f64 9..14
+//   sym_solve, sym_det, sym_matvec, sym_invert (full), batch_inv, batch_det: orders 9..16, f32 and f64
 #pragma once
 #include "nfm_common.hpp"
 

@@ -20,6 +20,66 @@ __device__ __forceinline__ float fma_(float a, float b, float c) { return __buil
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ----------------------------------------------------------------------------
+// Select policy of the pivoting code.
+//   Sel<false>: plain `c ? a : b` (orders <= 8: LLVM keeps these as v_cndmask).
+//   Sel<true> : an OPAQUE select -- one v_cndmask_b32 per 32-bit half under the wave mask of
+//               the condition, written as inline asm.  For orders >= 9 LLVM turns part of the
+//               fully unrolled select network into data-dependent branches; with hundreds of
+//               live values the register allocator then places spill code inside those
+//               divergent regions and hipcc 7.2 produces wrong, run-to-run varying results
+//               (scripts/dbg_stream.hip).  Opaque selects leave no data-dependent control flow
+//               (so every spill executes under a full EXEC mask) and, as a bonus, cut the
+//               register pressure (16x16 f32 inverse: 512 regs + scratch -> 341 regs).
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ int asel_(unsigned long long m, int a, int b)
+{
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float asel_(unsigned long long m, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ double asel_(unsigned long long m, double a, double b)
+{
+    union {
+        double d;
+        int i[2];
+    } ua, ub, ur;
+    ua.d = a;
+    ub.d = b;
+    ur.i[0] = asel_(m, ua.i[0], ub.i[0]);
+    ur.i[1] = asel_(m, ua.i[1], ub.i[1]);
+    return ur.d;
+}
+
+template <bool OPAQUE>
+struct Sel;
+template <>
+struct Sel<false> {
+    using M = bool;
+    static __device__ __forceinline__ M mask(bool c) { return c; }
+    template <typename T>
+    static __device__ __forceinline__ T pick(M m, T a, T b)
+    {
+        return m ? a : b;
+    }
+};
+template <>
+struct Sel<true> {
+    using M = unsigned long long;
+    static __device__ __forceinline__ M mask(bool c) { return __ballot(c); }
+    template <typename T>
+    static __device__ __forceinline__ T pick(M m, T a, T b)
+    {
+        return asel_(m, a, b);
+    }
+};
+
+// ----------------------------------------------------------------------------
 // compact symmetric, closed forms (M <= 4)
 // ----------------------------------------------------------------------------
 
@@ -221,6 +281,7 @@ __device__ __forceinline__ void sym_expand(const T (&m)[sym_k(M)], T (&a)[M][M])
 template <typename T, int N, int NR>
 __device__ __forceinline__ void ge_solve(T (&a)[N][N], T (&b)[N][NR])
 {
+    using S = Sel<(N > 8)>;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         if constexpr (N > 1) {
@@ -229,24 +290,24 @@ __device__ __forceinline__ void ge_solve(T (&a)[N][N], T (&b)[N][NR])
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
                 const T x = fabs_(a[i][k]);
-                const bool g = x > best;
-                best = g ? x : best;
-                p = g ? i : p;
+                const typename S::M g = S::mask(x > best);
+                best = S::pick(g, x, best);
+                p = S::pick(g, i, p);
             }
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
-                const bool s = (p == i);
+                const typename S::M s = S::mask(p == i);
 #pragma unroll
                 for (int j = k; j < N; ++j) {
                     const T t = a[k][j];
-                    a[k][j] = s ? a[i][j] : t;
-                    a[i][j] = s ? t : a[i][j];
+                    a[k][j] = S::pick(s, a[i][j], t);
+                    a[i][j] = S::pick(s, t, a[i][j]);
                 }
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const T t = b[k][r];
-                    b[k][r] = s ? b[i][r] : t;
-                    b[i][r] = s ? t : b[i][r];
+                    b[k][r] = S::pick(s, b[i][r], t);
+                    b[i][r] = S::pick(s, t, b[i][r]);
                 }
             }
         }
@@ -278,6 +339,7 @@ __device__ __forceinline__ void ge_solve(T (&a)[N][N], T (&b)[N][NR])
 template <typename T, int N>
 __device__ __forceinline__ void gj_inverse(T (&a)[N][N])
 {
+    using S = Sel<(N > 8)>;
     int piv[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -287,18 +349,18 @@ __device__ __forceinline__ void gj_inverse(T (&a)[N][N])
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
                 const T x = fabs_(a[i][k]);
-                const bool g = x > best;
-                best = g ? x : best;
-                p = g ? i : p;
+                const typename S::M g = S::mask(x > best);
+                best = S::pick(g, x, best);
+                p = S::pick(g, i, p);
             }
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
-                const bool s = (p == i);
+                const typename S::M s = S::mask(p == i);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const T t = a[k][j];
-                    a[k][j] = s ? a[i][j] : t;
-                    a[i][j] = s ? t : a[i][j];
+                    a[k][j] = S::pick(s, a[i][j], t);
+                    a[i][j] = S::pick(s, t, a[i][j]);
                 }
             }
         }
@@ -322,12 +384,12 @@ __device__ __forceinline__ void gj_inverse(T (&a)[N][N])
     for (int k = N - 2; k >= 0; --k) {
 #pragma unroll
         for (int c = k + 1; c < N; ++c) {
-            const bool s = (piv[k] == c);
+            const typename S::M s = S::mask(piv[k] == c);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const T t = a[i][k];
-                a[i][k] = s ? a[i][c] : t;
-                a[i][c] = s ? t : a[i][c];
+                a[i][k] = S::pick(s, a[i][c], t);
+                a[i][c] = S::pick(s, t, a[i][c]);
             }
         }
         if constexpr (N > 8) __builtin_amdgcn_sched_barrier(0);
@@ -341,6 +403,7 @@ __device__ __forceinline__ void gj_inverse(T (&a)[N][N])
 template <typename T, int N>
 __device__ __forceinline__ void lu_factor_rowid(T (&a)[N][N], int (&rowid)[N])
 {
+    using S = Sel<(N > 8)>;
 #pragma unroll
     for (int i = 0; i < N; ++i) rowid[i] = i;
 #pragma unroll
@@ -351,22 +414,22 @@ __device__ __forceinline__ void lu_factor_rowid(T (&a)[N][N], int (&rowid)[N])
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
                 const T x = fabs_(a[i][k]);
-                const bool g = x > best;
-                best = g ? x : best;
-                p = g ? i : p;
+                const typename S::M g = S::mask(x > best);
+                best = S::pick(g, x, best);
+                p = S::pick(g, i, p);
             }
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
-                const bool s = (p == i);
+                const typename S::M s = S::mask(p == i);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const T t = a[k][j];
-                    a[k][j] = s ? a[i][j] : t;
-                    a[i][j] = s ? t : a[i][j];
+                    a[k][j] = S::pick(s, a[i][j], t);
+                    a[i][j] = S::pick(s, t, a[i][j]);
                 }
                 const int ti = rowid[k];
-                rowid[k] = s ? rowid[i] : ti;
-                rowid[i] = s ? ti : rowid[i];
+                rowid[k] = S::pick(s, rowid[i], ti);
+                rowid[i] = S::pick(s, ti, rowid[i]);
             }
         }
         const T rp = T(1) / a[k][k];
@@ -387,8 +450,9 @@ __device__ __forceinline__ void lu_factor_rowid(T (&a)[N][N], int (&rowid)[N])
 template <typename T, int N>
 __device__ __forceinline__ void lu_solve_unit(const T (&lu)[N][N], const int (&rowid)[N], int c, T (&x)[N])
 {
+    using S = Sel<(N > 8)>;
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = (rowid[i] == c) ? T(1) : T(0);
+    for (int i = 0; i < N; ++i) x[i] = S::pick(S::mask(rowid[i] == c), T(1), T(0));
 #pragma unroll
     for (int i = 1; i < N; ++i) {
         T s = x[i];
@@ -412,6 +476,7 @@ __device__ __forceinline__ void lu_solve_unit(const T (&lu)[N][N], const int (&r
 template <typename T, int N>
 __device__ __forceinline__ T lu_det(T (&a)[N][N])
 {
+    using S = Sel<(N > 8)>;
     T det = T(1);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -421,21 +486,21 @@ __device__ __forceinline__ T lu_det(T (&a)[N][N])
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
                 const T x = fabs_(a[i][k]);
-                const bool g = x > best;
-                best = g ? x : best;
-                p = g ? i : p;
+                const typename S::M g = S::mask(x > best);
+                best = S::pick(g, x, best);
+                p = S::pick(g, i, p);
             }
 #pragma unroll
             for (int i = k + 1; i < N; ++i) {
-                const bool s = (p == i);
+                const typename S::M s = S::mask(p == i);
 #pragma unroll
                 for (int j = k; j < N; ++j) {
                     const T t = a[k][j];
-                    a[k][j] = s ? a[i][j] : t;
-                    a[i][j] = s ? t : a[i][j];
+                    a[k][j] = S::pick(s, a[i][j], t);
+                    a[i][j] = S::pick(s, t, a[i][j]);
                 }
             }
-            det = (p != k) ? -det : det;
+            det = S::pick(S::mask(p != k), -det, det);
         }
         const T pivot = a[k][k];
         const T rp = T(1) / pivot;

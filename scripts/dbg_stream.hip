@@ -6,6 +6,29 @@
 #include "../nitorch_fastmath_amd/csrc/nfm_batched_ops.hpp"
 using namespace nfm;
 
+// opaque select: one v_cndmask per 32-bit half under a wave mask, invisible to LLVM's
+// select <-> branch transformations
+__device__ __forceinline__ float asel(unsigned long long m, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int asel(unsigned long long m, int a, int b)
+{
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ double asel(unsigned long long m, double a, double b)
+{
+    union { double d; int i[2]; } ua, ub, ur;
+    ua.d = a; ub.d = b;
+    ur.i[0] = asel(m, ua.i[0], ub.i[0]);
+    ur.i[1] = asel(m, ua.i[1], ub.i[1]);
+    return ur.d;
+}
+
 template <typename T, int N, bool SB>
 __device__ __forceinline__ void lu_f(T (&a)[N][N], T (&rowid)[N])
 {
@@ -18,22 +41,22 @@ __device__ __forceinline__ void lu_f(T (&a)[N][N], T (&rowid)[N])
 #pragma unroll
         for (int i = k + 1; i < N; ++i) {
             const T x = fabs_(a[i][k]);
-            const bool g = x > best;
-            best = g ? x : best;
-            p = g ? i : p;
+            const unsigned long long g = __ballot(x > best);
+            best = asel(g, x, best);
+            p = asel(g, i, p);
         }
 #pragma unroll
         for (int i = k + 1; i < N; ++i) {
-            const bool s = (p == i);
+            const unsigned long long s = __ballot(p == i);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const T t = a[k][j];
-                a[k][j] = s ? a[i][j] : t;
-                a[i][j] = s ? t : a[i][j];
+                a[k][j] = asel(s, a[i][j], t);
+                a[i][j] = asel(s, t, a[i][j]);
             }
             const T ti = rowid[k];
-            rowid[k] = s ? rowid[i] : ti;
-            rowid[i] = s ? ti : rowid[i];
+            rowid[k] = asel(s, rowid[i], ti);
+            rowid[i] = asel(s, ti, rowid[i]);
         }
         const T rp = T(1) / a[k][k];
 #pragma unroll
@@ -50,7 +73,7 @@ template <typename T, int N, bool SB>
 __device__ __forceinline__ void lu_s(const T (&lu)[N][N], const T (&rowid)[N], int c, T (&x)[N])
 {
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = (rowid[i] == T(c)) ? T(1) : T(0);
+    for (int i = 0; i < N; ++i) x[i] = asel(__ballot(rowid[i] == T(c)), T(1), T(0));
 #pragma unroll
     for (int i = 1; i < N; ++i) {
         T s = x[i];
