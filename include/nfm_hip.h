@@ -162,26 +162,41 @@ size_t nfm_reduce_workspace_bytes(void);
 int nfm_reduce_all(int dtype, int op, int out_dtype, int64_t n, const void *x, void *workspace,
                    size_t workspace_bytes, void *out, void *stream);
 
-/* Reduction over the middle axis of a contiguous (outer, red, inner) view; out is
- * (outer, inner) of `out_dtype`; idx (may be NULL; max/min ops only) receives the
- * int64 position along `red` of the selected element (first occurrence). */
+/* Reduction over the middle axis of a contiguous (outer, red, inner) view
+ * (`_reduce_index` / `sum` with `dim=`, `reduce.py:49-142`, `:431-510`); out is (outer, inner)
+ * of `out_dtype`; idx (may be NULL; max/min ops only) receives the int64 position along `red`
+ * of the selected element (first occurrence).  Shapes with few outputs and a long reduced
+ * axis are cut into chunks reduced in parallel and folded in a fixed order: they need
+ * nfm_reduce_dim_workspace_bytes(...) bytes of device workspace (0 for the other shapes;
+ * workspace may then be NULL).  The plan depends on the shape only: results are reproducible. */
+size_t nfm_reduce_dim_workspace_bytes(int dtype, int op, int64_t outer, int64_t red, int64_t inner,
+                                      int want_idx);
 int nfm_reduce_dim(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner,
-                   const void *x, void *out, int64_t *idx, void *stream);
-
-/* Same reduction as nfm_reduce_dim (values only) for "few outputs, long reduced axis"
- * shapes: the reduced axis is cut into `nchunk` ranges reduced in parallel, partials
- * (nchunk * outer * inner doubles in `workspace`) folded by a second kernel in fixed order. */
-int nfm_reduce_dim_split(int dtype, int op, int out_dtype, int64_t outer, int64_t red, int64_t inner,
-                         int nchunk, const void *x, void *workspace, size_t workspace_bytes, void *out,
-                         void *stream);
+                   const void *x, void *workspace, size_t workspace_bytes, void *out, int64_t *idx,
+                   void *stream);
 
 /* One pass over a contiguous (outer, red, inner) view producing, per (outer, inner) entry,
  * four doubles [count, sum(x - K), sum((x - K)^2), K] over the non-NaN elements of the
- * reduced axis (K = a finite element of that slice, chosen by the kernel).  Feeds
- * `nanmean` / `nanvar` / `nanstd` / `mean` / `var` / `std` (`reduce.py:513-763`).
- * outer == inner == 1 takes the streaming full-reduction path and needs the workspace. */
+ * reduced axis (K = a finite element of that slice, chosen by the kernel).  The raw material
+ * of `nanmean` / `nanvar` / `nanstd` / `mean` / `var` / `std` (`reduce.py:513-763`).
+ * workspace: nfm_reduce_moments_workspace_bytes(...) bytes. */
+size_t nfm_reduce_moments_workspace_bytes(int dtype, int64_t outer, int64_t red, int64_t inner);
 int nfm_reduce_moments(int dtype, int64_t outer, int64_t red, int64_t inner, const void *x,
                        void *workspace, size_t workspace_bytes, double *out, void *stream);
+
+/* mean / var / std over the middle axis in ONE pass (the moments above, finished in the
+ * kernel): `mean` `reduce.py:513-550`, `nanmean :553-594`, `var :597-635`, `nanvar :638-685`,
+ * `std :688-726`, `nanstd :729-763`.  stat = NFM_STAT_MEAN|VAR|STD, or-ed with
+ * NFM_STAT_OMITNAN (ignore NaNs; otherwise a NaN in the slice gives NaN) and
+ * NFM_STAT_UNBIASED (var/std: multiply by n / (n - 1), `reduce.py:682-684`).
+ * out is (outer, inner) of `out_dtype`; workspace as for nfm_reduce_moments. */
+#define NFM_STAT_MEAN 0
+#define NFM_STAT_VAR 1
+#define NFM_STAT_STD 2
+#define NFM_STAT_OMITNAN 4
+#define NFM_STAT_UNBIASED 8
+int nfm_reduce_stat(int dtype, int stat, int out_dtype, int64_t outer, int64_t red, int64_t inner,
+                    const void *x, void *workspace, size_t workspace_bytes, void *out, void *stream);
 
 /* ------------------------------------------------------------------- qr ---- */
 /* Real dtypes.  Multi-output routines write ONE packed, contiguous output record per

@@ -43,9 +43,11 @@ SIGNATURES = {
     'nfm_batch_det': [_i, _i, _i64, _i64, _op, _op, _vp],
     'nfm_batch_matvec': [_i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_reduce_all': [_i, _i, _i, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
-    'nfm_reduce_dim': [_i, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
-    'nfm_reduce_dim_split': [_i, _i, _i, _i64, _i64, _i64, _i, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    'nfm_reduce_dim_workspace_bytes': [_i, _i, _i64, _i64, _i64, _i],
+    'nfm_reduce_dim': [_i, _i, _i, _i64, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp],
+    'nfm_reduce_moments_workspace_bytes': [_i, _i64, _i64, _i64],
     'nfm_reduce_moments': [_i, _i64, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    'nfm_reduce_stat': [_i, _i, _i, _i64, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
     'nfm_qr_givens': [_i, _i64, _i64, _op, _op, _vp, _vp],
     'nfm_qr_givens_apply': [_i, _i, _i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_qr_householder': [_i, _i, _i, _i64, _i64, _op, _vp, _vp],
@@ -72,7 +74,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_size_t if name.endswith('_workspace_bytes') else ctypes.c_int
         L.nfm_strerror.argtypes = [ctypes.c_int]
         L.nfm_strerror.restype = ctypes.c_char_p
         L.nfm_version.argtypes = []

@@ -44,9 +44,39 @@ def _prod(xs):
     return p
 
 
-def _workspace(dev):
-    n = _lib.lib().nfm_reduce_workspace_bytes()
+def _workspace(dev, nbytes=None):
+    n = _lib.lib().nfm_reduce_workspace_bytes() if nbytes is None else int(nbytes)
+    if n == 0:
+        return None, 0
     return torch.empty(n, dtype=torch.uint8, device=dev), n
+
+
+def _view3(input, dim):
+    """Contiguous (outer, red, inner) view of `input` for a reduction over `dim`.
+
+    Consecutive dims of a contiguous tensor are reduced in place; anything else is first
+    permuted so that the reduced dims are last (one copy).
+    Returns (x, outer, red, inner, dims, kept, redshape)."""
+    nd = input.dim()
+    if dim is None:
+        dims = list(range(nd))
+    else:
+        dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
+    if len(set(dims)) != len(dims) or builtins.min(dims, default=0) < 0 or builtins.max(dims, default=-1) >= nd:
+        raise IndexError(f'invalid reduction dims {dim} for a {nd}-d tensor')
+    shape = list(input.shape)
+    kept = [d for d in range(nd) if d not in dims]
+    redshape = [shape[d] for d in dims]
+    consecutive = len(dims) > 0 and dims == list(range(dims[0], dims[0] + len(dims)))
+    if nd == 0 or len(dims) == 0:
+        x, outer, red, inner = input.contiguous().reshape(-1), input.numel(), 1, 1
+    elif consecutive and input.is_contiguous():
+        x = input
+        outer, red, inner = _prod(shape[:dims[0]]), _prod(redshape), _prod(shape[dims[-1] + 1:])
+    else:
+        x = input.permute(kept + dims).contiguous()
+        outer, red, inner = _prod([shape[d] for d in kept]), _prod(redshape), 1
+    return x, outer, red, inner, dims, kept, redshape
 
 
 def _reduce(op, input, dim, keepdim, out_dtype, want_idx=False):
@@ -68,37 +98,18 @@ def _reduce(op, input, dim, keepdim, out_dtype, want_idx=False):
         if keepdim:
             out = out.reshape([1] * nd)
         return out, None, None, None
-    dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
-    if len(set(dims)) != len(dims) or builtins.min(dims, default=0) < 0 or builtins.max(dims, default=0) >= nd:
-        raise IndexError(f'invalid reduction dims {dim} for a {nd}-d tensor')
+    x, outer, red, inner, dims, kept, redshape = _view3(input, dim)
     shape = list(input.shape)
-    kept = [d for d in range(nd) if d not in dims]
-    redshape = [shape[d] for d in dims]
-    consecutive = dims == list(range(dims[0], dims[0] + len(dims)))
-    if consecutive and input.is_contiguous():
-        x = input
-        outer, red, inner = _prod(shape[:dims[0]]), _prod(redshape), _prod(shape[dims[-1] + 1:])
-    else:
-        x = input.permute(kept + dims).contiguous()
-        outer, red, inner = _prod([shape[d] for d in kept]), _prod(redshape), 1
     subshape = [shape[d] for d in kept]
     out = torch.empty(subshape, dtype=out_dtype, device=dev)
     idx = torch.empty(subshape, dtype=torch.long, device=dev) if want_idx else None
     if red == 0 and op in (_lib.RED_NANMAX, _lib.RED_NANMIN, _lib.RED_MAX, _lib.RED_MIN):
         raise IndexError('cannot take the max/min over an empty dimension')
-    nout = outer * inner
-    lanes = nout * (64 if inner == 1 else 1)
-    if idx is None and lanes < (1 << 19) and red >= 4096:
-        # few outputs, long reduced axis: cut the axis so that ~2^20 lanes are busy
-        nchunk = int(builtins.min(65535, builtins.max(2, (1 << 20) // builtins.max(lanes, 1)), red // 256))
-        ws = torch.empty(nchunk * nout, dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(L.nfm_reduce_dim_split(code, op, ocode, outer, red, inner, nchunk, x.data_ptr(), ws.data_ptr(),
-                                              ws.numel() * 8, out.data_ptr(), stream_ptr(dev)))
-    else:
-        with torch.cuda.device(dev):
-            _lib.check(L.nfm_reduce_dim(code, op, ocode, outer, red, inner, x.data_ptr(), out.data_ptr(),
-                                        idx.data_ptr() if idx is not None else None, stream_ptr(dev)))
+    ws, wsn = _workspace(dev, L.nfm_reduce_dim_workspace_bytes(code, op, outer, red, inner, int(want_idx)))
+    with torch.cuda.device(dev):
+        _lib.check(L.nfm_reduce_dim(code, op, ocode, outer, red, inner, x.data_ptr(),
+                                    ws.data_ptr() if ws is not None else None, wsn, out.data_ptr(),
+                                    idx.data_ptr() if idx is not None else None, stream_ptr(dev)))
     if keepdim:
         keptshape = [1 if d in dims else s for d, s in enumerate(shape)]
         out = out.reshape(keptshape)
@@ -131,10 +142,13 @@ def _reduce_index(op_plain, op_nan, input, dim, keepdim, omitnan, return_indices
     val = _deliver(val, out_val)
     if not return_indices:
         return val
-    sub = ind2sub(idx, redshape)          # (len(dim), ...)
-    sub = torch.movedim(sub, 0, -1)       # (..., len(dim))
-    if scalar_dim:
-        sub = sub[..., 0]
+    if len(redshape) == 1:                # one reduced dim: the position along it IS the sub-index
+        sub = idx if scalar_dim else idx.unsqueeze(-1)
+    else:
+        sub = ind2sub(idx, redshape)          # (len(dim), ...)
+        sub = torch.movedim(sub, 0, -1)       # (..., len(dim))
+        if scalar_dim:
+            sub = sub[..., 0]
     return val, _deliver(sub, out_ind)
 
 
@@ -214,31 +228,45 @@ def _moments(input, dim, keepdim):
     no_grad_required(input)
     code = dtype_code(input.dtype)
     L = _lib.lib()
-    nd = input.dim()
-    if dim is None:
-        dims = list(range(nd))
-    else:
-        dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
+    x, outer, red, inner, dims, kept, _ = _view3(input, dim)
     shape = list(input.shape)
-    kept = [d for d in range(nd) if d not in dims]
-    consecutive = len(dims) > 0 and dims == list(range(dims[0], dims[0] + len(dims)))
-    if nd == 0:
-        x, outer, red, inner = input.reshape(1), 1, 1, 1
-    elif consecutive and input.is_contiguous():
-        x = input
-        outer, red, inner = _prod(shape[:dims[0]]), _prod(shape[d] for d in dims), _prod(shape[dims[-1] + 1:])
-    else:
-        x = input.permute(kept + dims).contiguous()
-        outer, red, inner = _prod([shape[d] for d in kept]), _prod(shape[d] for d in dims), 1
     subshape = [shape[d] for d in kept]
     out = torch.zeros(subshape + [4], dtype=torch.float64, device=dev)
-    ws, wsn = _workspace(dev)
+    ws, wsn = _workspace(dev, L.nfm_reduce_moments_workspace_bytes(code, outer, red, inner))
     with torch.cuda.device(dev):
-        _lib.check(L.nfm_reduce_moments(code, outer, red, inner, x.data_ptr(), ws.data_ptr(), wsn,
+        _lib.check(L.nfm_reduce_moments(code, outer, red, inner, x.data_ptr(),
+                                        ws.data_ptr() if ws is not None else None, wsn,
                                         out.data_ptr(), stream_ptr(dev)))
     if keepdim:
         out = out.reshape([1 if d in dims else s for d, s in enumerate(shape)] + [4])
     return out[..., 0], out[..., 1], out[..., 2], out[..., 3], red
+
+
+_STAT_MEAN, _STAT_VAR, _STAT_STD, _STAT_OMITNAN, _STAT_UNBIASED = 0, 1, 2, 4, 8
+
+
+def _stat(kind, input, dim, keepdim, omitnan, unbiased, out_dtype):
+    """mean / var / std in one pass (`nfm_reduce_stat`): moments finished inside the kernel."""
+    input = torch.as_tensor(input)
+    dev = require_gpu(input)
+    no_grad_required(input)
+    code = dtype_code(input.dtype)
+    ocode = dtype_code(out_dtype)
+    L = _lib.lib()
+    x, outer, red, inner, dims, kept, _ = _view3(input, dim)
+    shape = list(input.shape)
+    out = torch.empty([shape[d] for d in kept], dtype=out_dtype, device=dev)
+    if out.numel() and red == 0:
+        out.fill_(float('nan'))
+    stat = kind | (_STAT_OMITNAN if omitnan else 0) | (_STAT_UNBIASED if unbiased else 0)
+    ws, wsn = _workspace(dev, L.nfm_reduce_moments_workspace_bytes(code, outer, red, inner))
+    with torch.cuda.device(dev):
+        _lib.check(L.nfm_reduce_stat(code, stat, ocode, outer, red, inner, x.data_ptr(),
+                                     ws.data_ptr() if ws is not None else None, wsn,
+                                     out.data_ptr(), stream_ptr(dev)))
+    if keepdim:
+        out = out.reshape([1 if d in dims else s for d, s in enumerate(shape)])
+    return out
 
 
 def mean(input, dim=None, keepdim=False, omitnan=False, inplace=False, dtype=None, out=None):
@@ -246,22 +274,7 @@ def mean(input, dim=None, keepdim=False, omitnan=False, inplace=False, dtype=Non
     input = torch.as_tensor(input)
     if _needs_grad(input):
         return _deliver(_SumFn().apply(input, dim, keepdim, omitnan, True, dtype), out)
-    odt = dtype or input.dtype
-    w, s, _, k, red = _moments(input, dim, keepdim)
-    m = k + s / w
-    if not omitnan:   # a NaN anywhere in the reduced block propagates (torch.mean)
-        m = torch.where(w == red, m, torch.full_like(m, float('nan')))
-        # infinities: the shifted sum cannot represent them; fall back to the plain sum there
-        bad = ~torch.isfinite(m) & (w == red)
-        if bool(bad.any()):
-            s2, _, _, _ = _reduce(_lib.RED_SUM, input, dim, keepdim, torch.float64)
-            m = torch.where(bad, s2 / red, m)
-    else:
-        bad = ~torch.isfinite(m) & (w > 0)
-        if bool(bad.any()):
-            s2, _, _, _ = _reduce(_lib.RED_NANSUM, input, dim, keepdim, torch.float64)
-            m = torch.where(bad, s2 / w, m)
-    return _deliver(m.to(odt), out)
+    return _deliver(_stat(_STAT_MEAN, input, dim, keepdim, omitnan, False, dtype or input.dtype), out)
 
 
 def nanmean(input, dim=None, keepdim=False, inplace=False, dtype=None, out=None):
@@ -269,21 +282,10 @@ def nanmean(input, dim=None, keepdim=False, inplace=False, dtype=None, out=None)
     return mean(input, dim, keepdim, True, inplace, dtype, out)
 
 
-def _nanvar64(input, dim, keepdim, unbiased):
-    w, s, q, _, red = _moments(input, dim, keepdim)
-    v = ((q - s * s / w) / w).clamp_min_(0)
-    if unbiased:
-        v = v * (w / (w - 1))       # `reduce.py:682-684`
-    return v, w, red
-
-
 def var(input, dim=None, keepdim=False, unbiased=True, omitnan=False, inplace=False, dtype=None, out=None):
     """Variance of a tensor (`reduce.py:597-635`; the non-NaN form raises upstream, quirk Q13)."""
     input = torch.as_tensor(input)
-    v, w, red = _nanvar64(input, dim, keepdim, unbiased)
-    if not omitnan:   # a NaN anywhere in the reduced block propagates
-        v = torch.where(w == red, v, torch.full_like(v, float('nan')))
-    return _deliver(v.to(dtype or input.dtype), out)
+    return _deliver(_stat(_STAT_VAR, input, dim, keepdim, omitnan, unbiased, dtype or input.dtype), out)
 
 
 def nanvar(input, dim=None, keepdim=False, unbiased=True, inplace=False, dtype=None, out=None):
@@ -294,8 +296,7 @@ def nanvar(input, dim=None, keepdim=False, unbiased=True, inplace=False, dtype=N
 def std(input, dim=None, keepdim=False, unbiased=True, omitnan=False, inplace=False, dtype=None, out=None):
     """Standard deviation of a tensor (`reduce.py:688-726`)."""
     input = torch.as_tensor(input)
-    v = var(input, dim, keepdim, unbiased, omitnan, inplace, torch.float64)
-    return _deliver(v.sqrt_().to(dtype or input.dtype), out)
+    return _deliver(_stat(_STAT_STD, input, dim, keepdim, omitnan, unbiased, dtype or input.dtype), out)
 
 
 def nanstd(input, dim=None, keepdim=False, unbiased=True, inplace=False, dtype=None, out=None):

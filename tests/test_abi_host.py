@@ -69,7 +69,18 @@ def test_argument_validation_without_gpu(L):
     assert L.nfm_qr_householder(1, 4, 4, 1, 1, r, 8, None) == -1               # basis out of range
     assert L.nfm_qr_householder_apply(1, 4, 5, 0, 1, 1, r, r, None) == -1      # reflector longer than n
     assert L.nfm_qr_hessenberg(0, 3, 0, 1, 0, 1, 0, r, None, None) == 0        # empty batch
-    assert L.nfm_reduce_dim_split(0, 0, 0, 1, 10, 1, 0, None, 8, 64, 8, None) == -1
+    assert L.nfm_reduce_dim(0, 99, 0, 1, 10, 1, 16, None, 0, 16, None, None) == -1       # bad op
+    assert L.nfm_reduce_dim(0, 0, 0, 1, 10, 1, 6, None, 0, 16, None, None) == -4        # misaligned input
+    assert L.nfm_reduce_dim(0, 0, 0, 0, 10, 1, None, None, 0, None, None, None) == 0    # empty
+    # few outputs + long axis needs the chunk workspace; short rows need none
+    assert L.nfm_reduce_dim_workspace_bytes(0, 0, 1 << 20, 8, 1, 0) == 0
+    need = L.nfm_reduce_dim_workspace_bytes(0, 0, 16, 1 << 26, 1, 0)
+    assert need > 0 and L.nfm_reduce_dim_workspace_bytes(0, 1, 16, 1 << 26, 1, 1) == 2 * need
+    assert L.nfm_reduce_dim(0, 0, 0, 16, 1 << 26, 1, 16, None, 0, 16, None, None) == -1
+    assert L.nfm_reduce_dim(0, 0, 0, 16, 1 << 26, 1, 16, 16, 8, 16, None, None) == -5
+    assert L.nfm_reduce_moments_workspace_bytes(0, 1, 1000, 1) >= L.nfm_reduce_workspace_bytes()
+    assert L.nfm_reduce_stat(0, 3, 0, 1, 10, 1, 16, None, 0, 16, None) == -1            # bad stat kind
+    assert L.nfm_reduce_stat(0, 16, 0, 1, 10, 1, 16, None, 0, 16, None) == -1           # bad flag
     assert L.nfm_reduce_moments(3, 1, 1, 1, None, None, 0, None, None) == -2
     bad = Operand(6, 0, 0, 0, 1)   # misaligned for float
     assert L.nfm_sym_det(0, 3, 1, 1, ctypes.byref(bad), ctypes.byref(bad), None) == -4

@@ -181,7 +181,7 @@ def test_large_full_reduction_properties(dev):
 
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 def test_skinny_shapes_split_path(dev, dn):
-    """few outputs, long reduced axis: the split kernels (nfm_reduce_dim_split)"""
+    """few outputs, long reduced axis: chunked plans (partials folded by the second kernel)"""
     dtype = np.float32 if dn == 'f32' else np.float64
     rng = np.random.default_rng(21)
     tol = 2e-6 if dn == 'f32' else 1e-12
@@ -200,8 +200,91 @@ def test_skinny_shapes_split_path(dev, dn):
         assert np.array_equal(R().nanmin(xd, dim=dim).cpu().numpy(), np.nanmin(x, axis=dim))
         m = R().max(xd, dim=dim).cpu().numpy()
         assert np.array_equal(np.isnan(m), np.isnan(x).any(axis=dim))
-        # indices still come from the one-kernel path
         v, i = R().nanmax(xd, dim=dim, return_indices=True)
         assert np.array_equal(i.cpu().numpy(), np.where(np.isnan(x), -np.inf, x).argmax(axis=dim))
         mm = R().nanmean(xd, dim=dim, dtype=torch.float64).cpu().numpy()
         assert np.abs(mm - np.nanmean(x64, axis=dim)).max() <= 1e-12 * max(1.0, np.abs(x64[~np.isnan(x64)]).max())
+
+
+def _check_dim(x, xd, dim, dn):
+    """every dim-wise op of one (shape, dim) against numpy's nan-functions"""
+    import warnings
+    tol = 2e-6 if dn == 'f32' else 1e-12
+    x64 = x.astype(np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        e = np.nansum(x64, axis=dim)
+        scale = np.nansum(np.abs(x64), axis=dim) + 1e-300
+        r = R().nansum(xd, dim=dim, dtype=torch.float64).cpu().numpy()
+        assert r.shape == e.shape and (np.abs(r - e) <= 1e-12 * scale).all()
+        assert (np.abs(R().nansum(xd, dim=dim).cpu().numpy() - e) <= tol * scale).all()
+        s = R().sum(xd, dim=dim).cpu().numpy()
+        assert np.array_equal(np.isnan(s), np.isnan(x).any(axis=dim))
+        for name, fill, arg in (('nanmax', -np.inf, 'argmax'), ('nanmin', np.inf, 'argmin')):
+            xx = np.where(np.isnan(x), fill, x)
+            ev = getattr(xx, name[3:])(axis=dim)
+            assert np.array_equal(getattr(R(), name)(xd, dim=dim).cpu().numpy(), ev), name
+            v, i = getattr(R(), name)(xd, dim=dim, return_indices=True)
+            assert np.array_equal(v.cpu().numpy(), ev), name
+            assert np.array_equal(i.cpu().numpy(), getattr(xx, arg)(axis=dim)), name + ' index'
+        v, i = R().max(xd, dim=dim, return_indices=True)
+        anyn = np.isnan(x).any(axis=dim)
+        assert np.array_equal(np.isnan(v.cpu().numpy()), anyn)
+        ei = np.where(anyn, np.isnan(x).argmax(axis=dim), np.nan_to_num(x, nan=-np.inf).argmax(axis=dim))
+        assert np.array_equal(i.cpu().numpy(), ei), 'first-NaN index'
+        big = max(1.0, float(np.nanmax(np.abs(x64)))) if np.isfinite(x64).any() else 1.0
+        m, em = R().nanmean(xd, dim=dim, dtype=torch.float64).cpu().numpy(), np.nanmean(x64, axis=dim)
+        assert np.array_equal(np.isnan(m), np.isnan(em)) and np.nanmax(np.abs(m - em), initial=0) <= 1e-12 * big
+        m = R().mean(xd, dim=dim).cpu().numpy()
+        assert np.array_equal(np.isnan(m), anyn)
+        for unb in (True, False):
+            r = R().nanvar(xd, dim=dim, unbiased=unb, dtype=torch.float64).cpu().numpy()
+            ev = np.nanvar(x64, axis=dim, ddof=int(unb))
+            ok = np.isfinite(ev)
+            assert np.array_equal(np.isnan(r[~ok]), np.isnan(ev[~ok]))
+            assert np.abs(r[ok] - ev[ok]).max(initial=0) <= 1e-11 * big * big
+            r = R().nanstd(xd, dim=dim, unbiased=unb).cpu().numpy()
+            assert np.abs(r[ok] - np.sqrt(ev[ok])).max(initial=0) <= tol * 20 * big
+
+
+# (shape, dim): every plan of nfm_reduce_dim.hip -- SHORT rows (vector and scalar, every group
+# size), FLAT slabs (inner == 1, power-of-two / odd / large small-inner, ragged ends, chunked),
+# COL (vector and scalar, chunked and not)
+_PLAN_SHAPES = [
+    ((1000, 1), 1), ((1000, 2), 1), ((999, 3), 1), ((1000, 4), 1), ((777, 8), 1), ((513, 12), 1),
+    ((300, 32), 1), ((129, 100), 1), ((67, 256), 1), ((67, 255), 1), ((50, 64), 1), ((50, 65), 1),
+    ((33, 1000), 1), ((9, 4096), 1), ((3, 100_001), 1), ((1, 1_000_003), 1), ((20_000, 260), 1),
+    ((5, 700, 2), 1), ((5, 701, 3), 1), ((4, 300, 4), 1), ((3, 1000, 5), 1), ((7, 130, 8), 1),
+    ((2, 5000, 10), 1), ((1, 100_000, 16), 1), ((3, 333, 37), 1), ((2, 250, 64), 1), ((2, 90, 100), 1),
+    ((3, 70, 128), 1), ((2, 40, 256), 1), ((1, 200_001, 3), 1), ((600, 4, 4), 1), ((10_000, 3, 3), 1),
+    ((2, 300, 1000), 1), ((3, 50, 1001), 1), ((1, 7, 100_000), 1), ((1, 3000, 260), 1),
+    ((1, 5000, 515), 1), ((2, 8, 65_536), 1), ((1, 100_000, 300), 1),
+]
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_dim_kernel_plans(dev, dn):
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(77)
+    for shape, dim in _PLAN_SHAPES:
+        x = rng.standard_normal(shape).astype(dtype)
+        x[rng.random(shape) < 0.03] = np.nan
+        x[rng.random(shape) < 0.05] = 1.5            # ties: first occurrence must win
+        if x.shape[0] > 1:
+            x[1].fill(np.nan)                         # all-NaN slices
+        _check_dim(x, t(x, dev), dim, dn)
+        if x.size < 300_000:                          # misaligned base pointer: scalar plans
+            flat = np.concatenate([np.zeros(1, dtype), x.reshape(-1)])
+            xd = t(flat, dev)[1:].reshape(shape)
+            _check_dim(x, xd, dim, dn)
+
+
+def test_dim_reductions_are_reproducible(dev):
+    g = torch.Generator(device=dev).manual_seed(5)
+    for shape in ((16, 1 << 20), (1, 1 << 18, 12), (1 << 12, 300), (2, 1 << 16, 512)):
+        x = torch.randn(shape, device=dev, generator=g)
+        a = R().nansum(x, dim=1)
+        for _ in range(3):
+            assert torch.equal(a, R().nansum(x, dim=1))
+        v = R().nanvar(x, dim=1)
+        assert torch.equal(v, R().nanvar(x, dim=1))
