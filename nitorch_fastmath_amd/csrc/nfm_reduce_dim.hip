@@ -190,7 +190,9 @@ struct MomAcc {
         } else {
             // (q - s^2 / n) / n * (n / (n - 1)) == (q - s^2 / n) / (n - 1): one division each
             const double ss = m.q - m.s * (m.s / m.n);
-            v = (ss < 0.0 ? 0.0 : ss) / ((f.stat & NFM_STAT_UNBIASED) ? m.n - 1.0 : m.n);
+            const double den = (f.stat & NFM_STAT_UNBIASED) ? m.n - 1.0 : m.n;
+            v = (ss < 0.0 ? 0.0 : ss) / den;
+            if (den <= 0.0) v = __builtin_nan(""); // fewer values than degrees of freedom (0 / 0 upstream)
             if (kind == NFM_STAT_STD) v = sqrt(v);
         }
         // without omitnan a NaN anywhere in the reduced slice propagates

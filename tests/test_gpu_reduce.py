@@ -257,7 +257,7 @@ _PLAN_SHAPES = [
     ((5, 700, 2), 1), ((5, 701, 3), 1), ((4, 300, 4), 1), ((3, 1000, 5), 1), ((7, 130, 8), 1),
     ((2, 5000, 10), 1), ((1, 100_000, 16), 1), ((3, 333, 37), 1), ((2, 250, 64), 1), ((2, 90, 100), 1),
     ((3, 70, 128), 1), ((2, 40, 256), 1), ((1, 200_001, 3), 1), ((600, 4, 4), 1), ((10_000, 3, 3), 1),
-    ((2, 300, 1000), 1), ((3, 50, 1001), 1), ((1, 7, 100_000), 1), ((1, 3000, 260), 1),
+    ((63, 3, 128), 1), ((2, 300, 1000), 1), ((3, 50, 1001), 1), ((1, 7, 100_000), 1), ((1, 3000, 260), 1),
     ((1, 5000, 515), 1), ((2, 8, 65_536), 1), ((1, 100_000, 300), 1),
 ]
 
