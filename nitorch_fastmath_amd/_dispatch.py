@@ -74,12 +74,17 @@ def _collapse(shape, strides_list):
 class Batch:
     """Broadcast batch of several operands flattened to (n_outer, n_inner)."""
 
-    def __init__(self, batch_shape, tensors, ncomp, _copyback=None):
+    def __init__(self, batch_shape, tensors, ncomp, _copyback=None, pack=False):
         # tensors[k] has shape batch_shape + comp dims (ncomp[k] trailing dims), already
         # expanded; the LAST tensor is the output.
+        # pack=True (orders 9..16): the register kernels of those orders only take batch-major
+        # contiguous records, and one packing copy (2x the operand's bytes at ~5 TB/s) is far
+        # cheaper than the LDS-resident strided fallback; broadcast operands are left alone.
         nb = len(batch_shape)
         self.shape = tuple(batch_shape)
         self._copyback = _copyback
+        if pack:
+            tensors = self._pack(tensors, nb)
         strides = [list(t.stride()[:nb]) for t in tensors]
         sizes, per_op = _collapse(self.shape, strides)
         if len(sizes) > 2:
@@ -121,6 +126,19 @@ class Batch:
                 sr, sc = 0, 0
             self.operands.append(_lib.Operand(t.data_ptr(), so, si, sr, sc))
 
+
+    def _pack(self, tensors, nb):
+        new = []
+        for k, t in enumerate(tensors):
+            bcast = any(st == 0 and sz > 1 for st, sz in zip(t.stride()[:nb], t.shape[:nb]))
+            if bcast or t.is_contiguous() or t.numel() == 0:
+                new.append(t)
+                continue
+            c = t.contiguous()
+            if k == len(tensors) - 1 and self._copyback is None:
+                self._copyback = (t, c)
+            new.append(c)
+        return new
 
     def _materialise(self, tensors):
         new = [t.contiguous() for t in tensors]

@@ -35,7 +35,7 @@ def batchdet(a):
     assert a.shape[-2] == n, 'Expected square matrices'
     batch = a.shape[:-2]
     out = torch.empty(batch, dtype=dtype, device=dev)
-    b = Batch(batch, [a, out], [2, 0])
+    b = Batch(batch, [a, out], [2, 0], pack=n > 8)
     o = b.operands
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nfm_batch_det(dtype_code(dtype), n, b.n_outer, b.n_inner,
@@ -59,7 +59,7 @@ def batchinv(a, perturb=False):
     assert a.shape[-2] == n, 'Expected square matrices'
     batch = a.shape[:-2]
     out = torch.empty(tuple(batch) + (n, n), dtype=dtype, device=dev)
-    b = Batch(batch, [a, out], [2, 2])
+    b = Batch(batch, [a, out], [2, 2], pack=n > 8)
     o = b.operands
     flags = _lib.FLAG_TS_PERTURB if perturb else 0
     with torch.cuda.device(dev):

@@ -102,7 +102,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
         ncs.append(1)
     ops.append(out)
     ncs.append(1)
-    b = Batch(batch, ops, ncs)
+    b = Batch(batch, ops, ncs, pack=N > 8 and kind == _lib.MAT_SYM)
     o = b.operands
     o_inp = ctypes.byref(o[2]) if inp is not None else None
     with torch.cuda.device(dev):
@@ -203,7 +203,8 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     matv, mat_nc = _full_view(mat, N, kind)
     batch = torch.broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
     out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev)
-    b = Batch(batch, [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1), out], [mat_nc, 1, 1])
+    b = Batch(batch, [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1), out], [mat_nc, 1, 1],
+              pack=N > 8 and kind == _lib.MAT_SYM)
     o = b.operands
     eps_p = None
     if eps is not None:
@@ -243,7 +244,7 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
     _check_order(M)
     batch = mat.shape[:-1]
     out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev)
-    b = Batch(batch, [mat, out], [1, 1])
+    b = Batch(batch, [mat, out], [1, 1], pack=M > 8 and not diag)
     o = b.operands
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nfm_sym_invert(
@@ -269,7 +270,7 @@ def sym_det(mat, dtype=None, out=None):
     _check_order(M)
     batch = mat.shape[:-1]
     out, _ = _alloc_out(out, tuple(batch), dtype, dev)
-    b = Batch(batch, [mat, out], [1, 0])
+    b = Batch(batch, [mat, out], [1, 0], pack=M > 8)
     o = b.operands
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nfm_sym_det(
