@@ -298,7 +298,10 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                 for (int i = 0; i < m; ++i) h[i][i] += sigma;
                 const T bb = fabs_(h[m - 1][m - 2]), a0 = fabs_(h[m - 1][m - 1]), a1 = fabs_(h[m - 2][m - 2]);
                 const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
-                if ((double)sos_lower < tol * (double)sos_diag) {
+                // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
+                // more: a zero off-diagonal (diagonal or zero blocks, padding lanes of the last
+                // tile) or NaNs would otherwise spin through all max_iter identical iterations
+                if ((double)sos_lower <= tol * (double)sos_diag || sos_lower != sos_lower) {
 #pragma unroll
                     for (int j = 0; j < m - 1; ++j) h[m - 1][j] = T(0);
                     break;

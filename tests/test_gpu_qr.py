@@ -205,3 +205,33 @@ def test_large_eig_3x3_properties(dev):
     ref = torch.linalg.eigvalsh(a[:4096].double().cpu())
     got = ev[:4096].double().cpu().sort(-1).values
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 5e-6
+
+
+def test_eig_sym_nothing_left_to_iterate(dev, oracle):
+    """zero / diagonal / block-diagonal input and the padding lanes of a ragged last tile have a
+    zero off-diagonal from the start: the iteration must stop at once (upstream would spin
+    through max_iter = 1024 identical sweeps) and return the diagonal."""
+    import nitorch_fastmath_amd as N
+    for dtype in (torch.float32, torch.float64):
+        z = torch.zeros(5, 4, 4, device=dev, dtype=dtype)
+        assert torch.equal(N.eig_sym(z), torch.zeros(5, 4, device=dev, dtype=dtype))
+        d = torch.diag_embed(torch.tensor([[3.0, -1.0, 2.0, 0.0]], device=dev, dtype=dtype)).repeat(7, 1, 1)
+        v, u = N.eig_sym(d, compute_u=True)
+        assert torch.equal(v.sort(-1).values, torch.tensor([-1.0, 0.0, 2.0, 3.0], device=dev, dtype=dtype).expand(7, 4))
+        e = oracle.eig_sym(d.cpu().numpy())
+        assert np.array_equal(v.cpu().numpy(), e)
+        # ragged batch (1000 = 15 * 64 + 40): the 24 idle lanes of the last wavefront must not
+        # keep it alive for 1024 sweeps (~1 ms); a converging batch takes tens of microseconds
+        g = torch.Generator(device=dev).manual_seed(3)
+        a = torch.randn(1000, 3, 3, device=dev, generator=g, dtype=dtype) + 8 * torch.eye(3, device=dev, dtype=dtype)
+        s = (a + a.transpose(-1, -2)).contiguous()
+        N.eig_sym(s, check_finite=False)
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            N.eig_sym(s, check_finite=False)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        assert best < 0.5, f'eig_sym on a ragged batch took {best:.3f} ms'
