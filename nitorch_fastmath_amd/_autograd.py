@@ -11,7 +11,7 @@ import ctypes
 import torch
 from torch.autograd.function import once_differentiable
 from . import _lib
-from ._dispatch import Batch, dtype_code, expand_batch, stream_ptr
+from ._dispatch import Batch, dtype_code, expand_batch, stream_ptr, broadcast_shapes
 
 
 def needs_grad(*tensors):
@@ -29,7 +29,7 @@ def sym_outer2(x, y, neg=False):
     """compact pull-back of x y^T: out_ii = x_i y_i, out_ij = x_i y_j + x_j y_i (nfm_sym_outer2)."""
     dev, dtype = x.device, x.dtype
     M = x.shape[-1]
-    batch = torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    batch = broadcast_shapes(x.shape[:-1], y.shape[:-1])
     out = torch.empty(tuple(batch) + (M * (M + 1) // 2,), dtype=dtype, device=dev)
     b = Batch(batch, [expand_batch(batch, x, 1), expand_batch(batch, y, 1), out], [1, 1, 1])
     o = b.operands

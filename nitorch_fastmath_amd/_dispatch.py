@@ -42,6 +42,23 @@ def stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def broadcast_shapes(*shapes):
+    """`torch.broadcast_shapes` without its tracing machinery (12 us -> 1 us per call)."""
+    first = shapes[0]
+    if all(s == first for s in shapes[1:]):
+        return torch.Size(first)
+    nd = max(len(s) for s in shapes)
+    out = [1] * nd
+    for s in shapes:
+        for k in range(1, len(s) + 1):
+            d = s[-k]
+            if d != 1:
+                if out[-k] != 1 and out[-k] != d:
+                    raise RuntimeError(f'Shape mismatch: objects cannot be broadcast to a single shape: {shapes}')
+                out[-k] = d
+    return torch.Size(out)
+
+
 def common_dtype(dtype, *tensors):
     if dtype is not None:
         return dtype

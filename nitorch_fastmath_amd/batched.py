@@ -12,7 +12,7 @@ __all__ = ['batchmatvec', 'batchdet', 'batchinv']
 import ctypes
 import torch
 from . import _lib
-from ._dispatch import (Batch, common_dtype, dtype_code, expand_batch, no_grad_required,
+from ._dispatch import (Batch, broadcast_shapes, common_dtype, dtype_code, expand_batch, no_grad_required,
                         require_gpu, stream_ptr)
 
 
@@ -78,7 +78,7 @@ def batchmatvec(mat, vec):
     m, n = mat.shape[-2:]
     if vec.shape[-1] != n:
         raise ValueError(f'matrix {tuple(mat.shape[-2:])} and vector ({vec.shape[-1]},) do not match')
-    batch = torch.broadcast_shapes(mat.shape[:-2], vec.shape[:-1])
+    batch = broadcast_shapes(mat.shape[:-2], vec.shape[:-1])
     out = torch.empty(tuple(batch) + (m,), dtype=dtype, device=dev)
     b = Batch(batch, [expand_batch(batch, mat, 2), expand_batch(batch, vec, 1), out], [2, 1, 1])
     o = b.operands

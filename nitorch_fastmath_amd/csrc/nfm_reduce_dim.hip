@@ -44,6 +44,7 @@ struct ValAcc {
     __device__ __forceinline__ void init(const T *, int64_t, int64_t) { init_empty(); }
     template <int VEC>
     __device__ __forceinline__ void init_vals(const T (&)[VEC], bool) { init_empty(); }
+    __device__ __forceinline__ void init_own(T, bool) { init_empty(); }
     __device__ __forceinline__ void fold(T v, int64_t) { RedOp<OP>::fold(a, v); }
     __device__ __forceinline__ void merge(const ValAcc &o) { a = RedOp<OP>::merge(a, o.a); }
     __device__ __forceinline__ ValAcc shfl(int off) const
@@ -70,6 +71,7 @@ struct PickAcc {
     __device__ __forceinline__ void init(const T *, int64_t, int64_t) { init_empty(); }
     template <int VEC>
     __device__ __forceinline__ void init_vals(const T (&)[VEC], bool) { init_empty(); }
+    __device__ __forceinline__ void init_own(T, bool) { init_empty(); }
     __device__ __forceinline__ void fold(T v, int64_t r)
     {
         const T w = Pick<OP>::see(v);
@@ -138,6 +140,13 @@ struct MomAcc {
                 k = (d - d == 0.0) ? d : k;
             }
         }
+    }
+    // shift = this accumulator's own first value (one element per lane and column)
+    __device__ __forceinline__ void init_own(T v, bool have)
+    {
+        m = {0.0, 0.0, 0.0};
+        const double d = (double)v;
+        k = (have && d - d == 0.0) ? d : 0.0;
     }
     __device__ __forceinline__ void fold(T v, int64_t) { mom_fold(m, v, k); }
     // the two sides may use different shifts: re-centre the other side's sums on ours
@@ -287,8 +296,12 @@ __global__ __launch_bounds__(256) void reduce_group_k(const T *__restrict__ x, i
             const int64_t sl = s0 + (int64_t)p * spw;
             const bool have = sl < outer && in_slab;
             Acc acc[NA];
+            if constexpr (ONE) {
+                acc[0].template init_vals<VEC>(vals[p], have);
+            } else { // one element per lane and column: its own value is the shift
 #pragma unroll
-            for (int k = 0; k < NA; ++k) acc[k].template init_vals<VEC>(vals[p], have);
+                for (int k = 0; k < VEC; ++k) acc[k].init_own(vals[p][k], have);
+            }
             if (have) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[ONE ? 0 : k].fold(vals[p][k], r0[k]);
@@ -318,8 +331,15 @@ __global__ __launch_bounds__(256) void reduce_group_k(const T *__restrict__ x, i
         Acc acc[NA];
         T v0[VEC], v1[VEC], v2[VEC], v3[VEC];
         if (valid) LoadV<T, VEC>::ld(slab + pos0, v0);
+        if constexpr (ONE) {
+            acc[0].template init_vals<VEC>(v0, valid);
+        } else { // shift from the component's own column (first finite of its first elements)
 #pragma unroll
-        for (int k = 0; k < NA; ++k) acc[k].template init_vals<VEC>(v0, valid);
+            for (int k = 0; k < VEC; ++k) {
+                if (valid) acc[k].init(slab + (pos0 + k) % inner, L / inner, inner);
+                else acc[k].init_empty();
+            }
+        }
         if (valid) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[ONE ? 0 : k].fold(v0[k], r0[k]);

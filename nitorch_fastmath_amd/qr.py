@@ -30,7 +30,7 @@ __all__ = [
 import ctypes
 import torch
 from . import _lib
-from ._dispatch import Batch, dtype_code, expand_batch, no_grad_required, require_gpu, stream_ptr
+from ._dispatch import Batch, dtype_code, expand_batch, no_grad_required, require_gpu, stream_ptr, broadcast_shapes
 from .utils import ensure_list
 
 
@@ -138,7 +138,7 @@ def rq_hessenberg(h, u=None, inplace=False, check_finite=True):
     _check_finite(check_finite, h)
     _check_square(h)
     n = h.shape[-1]
-    batch = h.shape[:-2] if u is None else torch.broadcast_shapes(h.shape[:-2], u.shape[:-2])
+    batch = h.shape[:-2] if u is None else broadcast_shapes(h.shape[:-2], u.shape[:-2])
     out = _packed(batch, n * n * (2 if u is not None else 1), dtype, dev)
     L = _lib.lib()
     if u is None:
@@ -243,7 +243,7 @@ def householder_apply(a, u, k=None, side='both', inverse=False, inplace=False, c
     if side.lower() not in _lib.SIDE:
         raise ValueError(f'unknown side {side}')
     n = a.shape[-1]
-    batch = torch.broadcast_shapes(a.shape[:-2], *[uk.shape[:-1] for uk in us])
+    batch = broadcast_shapes(a.shape[:-2], *[uk.shape[:-1] for uk in us])
     out = expand_batch(batch, a, 2).clone(memory_format=torch.contiguous_format)
     if inverse:
         us = us[::-1]
@@ -264,7 +264,7 @@ def householder_apply(a, u, k=None, side='both', inverse=False, inplace=False, c
 def givens(x, y):
     r"""Givens rotation: ``c = x / norm([x, y])``, ``s = -y / norm([x, y])`` (`qr.py`, `_impl/qr.py:326-369`)."""
     dev, dtype, (x, y) = _prep(x, y)
-    batch = torch.broadcast_shapes(x.shape, y.shape)
+    batch = broadcast_shapes(x.shape, y.shape)
     out = _packed(batch, 2, dtype, dev)
     _run(_lib.lib().nfm_qr_givens, (dtype_code(dtype),), batch,
          [expand_batch(batch, x, 0), expand_batch(batch, y, 0)], [0, 0], dtype, dev, out)
@@ -285,7 +285,7 @@ def givens_apply(a, c, s, i=0, j=None, side='both', inplace=False, check_finite=
     j = i + 1 if j is None else j
     i = i if i >= 0 else n + i
     j = j if j >= 0 else n + j
-    vshape = torch.broadcast_shapes(a.shape[:-2] + (n,), c.shape, s.shape)
+    vshape = broadcast_shapes(a.shape[:-2] + (n,), c.shape, s.shape)
     batch = vshape[:-1]
     out = expand_batch(batch, a, 2).clone(memory_format=torch.contiguous_format)
     b = Batch(batch, [c.expand(vshape), s.expand(vshape), out], [1, 1, 2])

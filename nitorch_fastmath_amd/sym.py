@@ -28,7 +28,7 @@ import ctypes
 from math import sqrt
 import torch
 from . import _lib
-from ._dispatch import (Batch, common_dtype, dtype_code, expand_batch, no_grad_required,
+from ._dispatch import (Batch, broadcast_shapes, common_dtype, dtype_code, expand_batch, no_grad_required,
                         require_gpu, stream_ptr)
 
 
@@ -91,7 +91,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
     kind = _mat_kind(mat.shape[-1], N)
     matv, mat_nc = _full_view(mat, N, kind)
     shapes = [mat.shape[:-1], vec.shape[:-1]] + ([inp.shape[:-1]] if inp is not None else [])
-    batch = torch.broadcast_shapes(*shapes)
+    batch = broadcast_shapes(*shapes)
     if inp is not None and inp.shape[-1] != N:
         raise ValueError('inp and vec must have the same number of components')
     out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev)
@@ -150,7 +150,7 @@ def sym_addmatvec(inp, mat, vec, dtype=None, out=None):
 
 def sym_addmatvec_(inp, mat, vec):
     """In-place `inp += mat @ vec`."""
-    _require_inplace_ok(inp, torch.broadcast_shapes(mat.shape[:-1], vec.shape[:-1]) + vec.shape[-1:])
+    _require_inplace_ok(inp, broadcast_shapes(mat.shape[:-1], vec.shape[:-1]) + vec.shape[-1:])
     return _matvec_impl(+1, inp, mat, vec, inp.dtype, inp)
 
 
@@ -161,7 +161,7 @@ def sym_submatvec(inp, mat, vec, dtype=None, out=None):
 
 def sym_submatvec_(inp, mat, vec):
     """In-place `inp -= mat @ vec`."""
-    _require_inplace_ok(inp, torch.broadcast_shapes(mat.shape[:-1], vec.shape[:-1]) + vec.shape[-1:])
+    _require_inplace_ok(inp, broadcast_shapes(mat.shape[:-1], vec.shape[:-1]) + vec.shape[-1:])
     return _matvec_impl(-1, inp, mat, vec, inp.dtype, inp)
 
 
@@ -201,7 +201,7 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     _check_order(N)
     kind = _mat_kind(mat.shape[-1], N)
     matv, mat_nc = _full_view(mat, N, kind)
-    batch = torch.broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
+    batch = broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
     out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev)
     b = Batch(batch, [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1), out], [mat_nc, 1, 1],
               pack=N > 8 and kind == _lib.MAT_SYM)
@@ -223,7 +223,7 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
 
 def sym_solve_(mat, vec, eps=None):
     """In-place `sym_solve`: overwrites `vec` with `mat \\ vec` (`sym.py:33`)."""
-    _require_inplace_ok(vec, torch.broadcast_shapes(mat.shape[:-1], vec.shape[:-1]) + vec.shape[-1:])
+    _require_inplace_ok(vec, broadcast_shapes(mat.shape[:-1], vec.shape[:-1]) + vec.shape[-1:])
     return sym_solve(mat, vec, eps=eps, dtype=vec.dtype, out=vec)
 
 
@@ -338,7 +338,7 @@ def sym_matmul(j, h, dtype=None, out=None):
         hk = _lib.MAT_DIAG
     else:
         raise ValueError(f'hessian with {h.shape[-1]} components does not match k={k}')
-    batch = torch.broadcast_shapes(j.shape[:-2], h.shape[:-1])
+    batch = broadcast_shapes(j.shape[:-2], h.shape[:-1])
     out, _ = _alloc_out(out, tuple(batch) + (d * (d + 1) // 2,), dtype, dev)
     b = Batch(batch, [expand_batch(batch, j, 2), expand_batch(batch, h, 1), out], [2, 1, 1])
     o = b.operands
