@@ -127,7 +127,7 @@ struct MomAcc {
         m = {0.0, 0.0, 0.0};
         k = pick_shift(p0, cnt, stride);
     }
-    // shift = the first finite value among the lane's own elements (SHORT rows: no extra loads)
+    // shift = the first finite value among the lane's own elements (GROUP plan, inner == 1: no extra loads)
     template <int VEC>
     __device__ __forceinline__ void init_vals(const T (&v)[VEC], bool have)
     {

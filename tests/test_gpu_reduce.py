@@ -247,7 +247,7 @@ def _check_dim(x, xd, dim, dn):
             assert np.abs(r[ok] - np.sqrt(ev[ok])).max(initial=0) <= tol * 20 * big
 
 
-# (shape, dim): every plan of nfm_reduce_dim.hip -- SHORT rows (vector and scalar, every group
+# (shape, dim): every plan of nfm_reduce_dim.hip -- GROUP slabs (vector and scalar, every group
 # size), FLAT slabs (inner == 1, power-of-two / odd / large small-inner, ragged ends, chunked),
 # COL (vector and scalar, chunked and not)
 _PLAN_SHAPES = [
