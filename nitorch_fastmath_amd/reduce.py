@@ -79,11 +79,55 @@ def _view3(input, dim):
     return x, outer, red, inner, dims, kept, redshape
 
 
+def _dim_groups(input, dim):
+    """Sorted reduction dims split into runs of consecutive dims, or None when one kernel
+    (or the permuting copy) handles the request anyway."""
+    if dim is None or not input.is_contiguous():
+        return None
+    nd = input.dim()
+    dims = sorted({d if d >= 0 else nd + d for d in ensure_list(dim)})
+    if len(dims) != len(ensure_list(dim)) or (dims and (dims[0] < 0 or dims[-1] >= nd)):
+        return None   # duplicates / out of range: let the one-kernel path raise
+    groups = []
+    for d in dims:
+        if groups and d == groups[-1][-1] + 1:
+            groups[-1].append(d)
+        else:
+            groups.append([d])
+    return groups if len(groups) > 1 else None
+
+
+# what a later stage does with the partial results of an earlier one
+_STAGE2 = {_lib.RED_NANSUM: _lib.RED_NANSUM, _lib.RED_SUM: _lib.RED_SUM, _lib.RED_NANCOUNT: _lib.RED_SUM,
+           _lib.RED_NANSUMSQ: _lib.RED_SUM, _lib.RED_NANMAX: _lib.RED_NANMAX, _lib.RED_NANMIN: _lib.RED_NANMIN,
+           _lib.RED_MAX: _lib.RED_MAX, _lib.RED_MIN: _lib.RED_MIN}
+
+
+def _reduce_staged(op, input, groups, keepdim, out_dtype):
+    """Non-adjacent reduction dims (e.g. batch + spatial dims of a channel-first field): reduce
+    the runs of adjacent dims one after the other, last run first, instead of permuting the
+    whole tensor into a copy.  Sums travel between the stages in float64."""
+    sums = op in (_lib.RED_NANSUM, _lib.RED_SUM, _lib.RED_NANCOUNT, _lib.RED_NANSUMSQ)
+    y, stage_op = input, op
+    for g in reversed(groups):
+        last = g is groups[0]
+        y = _reduce(stage_op, y, g, False, out_dtype if last else (torch.float64 if sums else input.dtype))[0]
+        stage_op = _STAGE2[op]
+    if keepdim:
+        red = {d for g in groups for d in g}
+        y = y.reshape([1 if d in red else s for d, s in enumerate(input.shape)])
+    return y
+
+
 def _reduce(op, input, dim, keepdim, out_dtype, want_idx=False):
     """Run one reduction kernel.  Returns (values, flat_indices or None, dims, redshape)."""
     input = torch.as_tensor(input)
     dev = require_gpu(input)
     no_grad_required(input)
+    if not want_idx:
+        groups = _dim_groups(input, dim)
+        if groups is not None:
+            return _reduce_staged(op, input, groups, keepdim, out_dtype), None, None, None
     code = dtype_code(input.dtype)
     ocode = dtype_code(out_dtype)
     L = _lib.lib()
@@ -245,11 +289,51 @@ def _moments(input, dim, keepdim):
 _STAT_MEAN, _STAT_VAR, _STAT_STD, _STAT_OMITNAN, _STAT_UNBIASED = 0, 1, 2, 4, 8
 
 
+def _stat_staged(kind, input, groups, keepdim, omitnan, unbiased, out_dtype):
+    """mean / var / std over non-adjacent dims: one pass of raw moments over the last run of
+    adjacent dims, then the (small) per-slice moments are merged over the other dims with the
+    pairwise formulas (count-weighted means, sum of within- and between-slice squares)."""
+    last = groups[-1]
+    n, s_, q, k, _ = _moments(input, last, False)
+    rest = [d for g in groups[:-1] for d in g]
+    has = n > 0
+    safe_n = torch.where(has, n, torch.ones_like(n))
+    mean_i = torch.where(has, k + s_ / safe_n, torch.zeros_like(n))
+    m2_i = torch.where(has, q - s_ * s_ / safe_n, torch.zeros_like(n))
+    cnt = n.sum(dim=rest)
+    mean = (n * mean_i).sum(dim=rest) / cnt
+    if kind == _STAT_MEAN:
+        v = mean
+    else:
+        mexp = mean
+        for d in rest:
+            mexp = mexp.unsqueeze(d)
+        m2 = (m2_i + n * (mean_i - mexp) ** 2).sum(dim=rest)
+        den = cnt - 1 if unbiased else cnt
+        v = m2.clamp_min(0) / den
+        v = torch.where(den > 0, v, torch.full_like(v, float('nan')))
+        if kind == _STAT_STD:
+            v = v.sqrt()
+    if not omitnan:
+        total = 1
+        for g in groups:
+            for d in g:
+                total *= input.shape[d]
+        v = torch.where(cnt == total, v, torch.full_like(v, float('nan')))
+    if keepdim:
+        red = {d for g in groups for d in g}
+        v = v.reshape([1 if d in red else sz for d, sz in enumerate(input.shape)])
+    return v.to(out_dtype)
+
+
 def _stat(kind, input, dim, keepdim, omitnan, unbiased, out_dtype):
     """mean / var / std in one pass (`nfm_reduce_stat`): moments finished inside the kernel."""
     input = torch.as_tensor(input)
     dev = require_gpu(input)
     no_grad_required(input)
+    groups = _dim_groups(input, dim)
+    if groups is not None:
+        return _stat_staged(kind, input, groups, keepdim, omitnan, unbiased, out_dtype)
     code = dtype_code(input.dtype)
     ocode = dtype_code(out_dtype)
     L = _lib.lib()

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""4x4 / 6x6 fp32 sym_solve under the operand layouts the facade accepts without copies."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nitorch_fastmath_amd as N  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, reps=8):
+    fn(); fn(); torch.cuda.synchronize(); best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize(); best = min(best, e0.elapsed_time(e1) * 1e-3)
+    return best
+
+
+print('| layout | M | n | ms | solves/s | algorithmic GB/s |')
+print('|---|---|---|---|---|---|')
+for M in (4, 6):
+    K = M * (M + 1) // 2
+    n = 1 << 24
+    g = torch.Generator(device=dev).manual_seed(M)
+    mat = 0.3 * torch.randn(n, K, device=dev, generator=g) / M
+    mat[:, :M] += 2
+    vec = torch.randn(n, M, device=dev, generator=g)
+    out = torch.empty_like(vec)
+    cases = []
+    cases.append(('contiguous AoS', mat, vec, (K + 2 * M) * 4))
+    cases.append(('channel-first (SoA) views', mat.T.contiguous().T, vec.T.contiguous().T, (K + 2 * M) * 4))
+    cases.append(('one matrix, n vectors (broadcast mat)', mat[:1], vec, 2 * M * 4))
+    cases.append(('n matrices, one vector (broadcast vec)', mat, vec[:1], (K + M) * 4))
+    cases.append(('every other record (batch stride 2)', mat[::2], vec[::2], (K + 2 * M) * 4))
+    big = torch.randn(n // 2, K, 2, device=dev, generator=g)
+    big[:, :M, 0] += 4
+    cases.append(('component stride 2', big[..., 0], vec[:n // 2], (K + 2 * M) * 4))
+    m3 = mat.view(1 << 12, 1 << 12, K)[:, ::2]
+    v3 = vec.view(1 << 12, 1 << 12, M)[:, ::2]
+    cases.append(('two-level batch (rows of a strided 2-D field)', m3, v3, (K + 2 * M) * 4))
+    mis = torch.empty(n * K + 1, device=dev)[1:].view(n, K).copy_(mat)
+    cases.append(('base pointer off by 4 bytes', mis, vec, (K + 2 * M) * 4))
+    for name, m, v, bpu in cases:
+        nn = max(m.shape[:-1].numel(), v.shape[:-1].numel())
+        t = timeit(lambda: N.sym_solve(m, v))
+        print(f'| {name} | {M} | {nn:.2e} | {t * 1e3:.3f} | {nn / t:.3e} | {nn * bpu / t / 1e9:.0f} |')

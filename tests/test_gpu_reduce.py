@@ -288,3 +288,44 @@ def test_dim_reductions_are_reproducible(dev):
             assert torch.equal(a, R().nansum(x, dim=1))
         v = R().nanvar(x, dim=1)
         assert torch.equal(v, R().nanvar(x, dim=1))
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_non_adjacent_dims_staged(dev, dn):
+    """batch + spatial dims of a channel-first field: reduced run by run, no permuting copy"""
+    import warnings
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((3, 4, 9, 11, 5)) + 50.0).astype(dtype)
+    x[rng.random(x.shape) < 0.05] = np.nan
+    x[:, 2] = np.nan                               # one all-NaN channel
+    xd = t(x, dev)
+    x64 = x.astype(np.float64)
+    tol = 2e-6 if dn == 'f32' else 1e-12
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for dim in ((0, 2, 3, 4), (0, 2), (1, 3), (0, 4), (4, 0, 2)):
+            ax = tuple(dim)
+            e = np.nansum(x64, axis=ax)
+            scale = np.nansum(np.abs(x64), axis=ax) + 1e-300
+            r = R().nansum(xd, dim=dim).cpu().numpy()
+            assert r.shape == e.shape and (np.abs(r - e) <= tol * scale).all(), dim
+            assert R().nansum(xd, dim=dim, keepdim=True).shape == np.nansum(x64, axis=ax, keepdims=True).shape
+            assert np.array_equal(np.isnan(R().sum(xd, dim=dim).cpu().numpy()), np.isnan(x).any(axis=ax))
+            assert np.array_equal(R().nanmax(xd, dim=dim).cpu().numpy(),
+                                  np.where(np.isnan(x), -np.inf, x).max(axis=ax))
+            assert np.array_equal(R().nanmin(xd, dim=dim).cpu().numpy(),
+                                  np.where(np.isnan(x), np.inf, x).min(axis=ax))
+            m = R().nanmean(xd, dim=dim, dtype=torch.float64).cpu().numpy()
+            em = np.nanmean(x64, axis=ax)
+            assert np.array_equal(np.isnan(m), np.isnan(em)) and np.nanmax(np.abs(m - em), initial=0) <= 1e-10
+            assert np.array_equal(np.isnan(R().mean(xd, dim=dim).cpu().numpy()), np.isnan(x).any(axis=ax))
+            for unb in (True, False):
+                v = R().nanvar(xd, dim=dim, unbiased=unb, dtype=torch.float64).cpu().numpy()
+                ev = np.nanvar(x64, axis=ax, ddof=int(unb))
+                ok = np.isfinite(ev)
+                assert np.array_equal(np.isnan(v[~ok]), np.isnan(ev[~ok]))
+                assert np.abs(v[ok] - ev[ok]).max(initial=0) <= 1e-9
+                sd = R().nanstd(xd, dim=dim, unbiased=unb, keepdim=True)
+                assert sd.shape == np.nanstd(x64, axis=ax, keepdims=True).shape
+                assert np.abs(sd.cpu().numpy().reshape(ev.shape)[ok] - np.sqrt(ev[ok])).max(initial=0) <= tol * 100
