@@ -79,6 +79,34 @@ def _view3(input, dim):
     return x, outer, red, inner, dims, kept, redshape
 
 
+def _canon(input, dim):
+    """A non-contiguous tensor that is a dim permutation of a contiguous one (e.g. the
+    channel-last view of a channel-first field): return (contiguous view, mapped dims,
+    inverse permutation) so that the reduction runs in place instead of on a copy."""
+    if dim is None or input.is_contiguous() or input.dim() < 2:
+        return None
+    nd = input.dim()
+    st = input.stride()
+    perm = sorted(range(nd), key=lambda d: (-st[d], d))
+    xp = input.permute(perm)
+    if not xp.is_contiguous():
+        return None
+    inv = [0] * nd
+    for j, d in enumerate(perm):
+        inv[d] = j
+    scalar = not isinstance(dim, (list, tuple, range))
+    dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
+    if any(d < 0 or d >= nd for d in dims):
+        return None
+    mapped = [inv[d] for d in dims]
+    return xp, (mapped[0] if scalar else mapped), inv, dims
+
+
+def _uncanon(r, inv, dims, keepdim):
+    r = r.permute(inv)
+    return r if keepdim or not dims else r.squeeze(tuple(dims))
+
+
 def _dim_groups(input, dim):
     """Sorted reduction dims split into runs of consecutive dims, or None when one kernel
     (or the permuting copy) handles the request anyway."""
@@ -124,6 +152,14 @@ def _reduce(op, input, dim, keepdim, out_dtype, want_idx=False):
     input = torch.as_tensor(input)
     dev = require_gpu(input)
     no_grad_required(input)
+    canon = _canon(input, dim)
+    if canon is not None:
+        xp, mapped, inv, odims = canon
+        val, idx, dims, redshape = _reduce(op, xp, mapped, True, out_dtype, want_idx)
+        val = _uncanon(val, inv, odims, keepdim)
+        if idx is not None:
+            idx = _uncanon(idx, inv, odims, keepdim)
+        return val, idx, dims, redshape
     if not want_idx:
         groups = _dim_groups(input, dim)
         if groups is not None:
@@ -331,6 +367,10 @@ def _stat(kind, input, dim, keepdim, omitnan, unbiased, out_dtype):
     input = torch.as_tensor(input)
     dev = require_gpu(input)
     no_grad_required(input)
+    canon = _canon(input, dim)
+    if canon is not None:
+        xp, mapped, inv, odims = canon
+        return _uncanon(_stat(kind, xp, mapped, True, omitnan, unbiased, out_dtype), inv, odims, keepdim)
     groups = _dim_groups(input, dim)
     if groups is not None:
         return _stat_staged(kind, input, groups, keepdim, omitnan, unbiased, out_dtype)

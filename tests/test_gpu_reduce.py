@@ -329,3 +329,44 @@ def test_non_adjacent_dims_staged(dev, dn):
                 sd = R().nanstd(xd, dim=dim, unbiased=unb, keepdim=True)
                 assert sd.shape == np.nanstd(x64, axis=ax, keepdims=True).shape
                 assert np.abs(sd.cpu().numpy().reshape(ev.shape)[ok] - np.sqrt(ev[ok])).max(initial=0) <= tol * 100
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_permuted_contiguous_inputs_reduce_in_place(dev, dn):
+    """channel-last views of channel-first fields (a dim permutation of a contiguous tensor)
+    are reduced through the mapped dims of the underlying tensor: no copy, same results"""
+    import warnings
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((2, 6, 7, 9, 5)).astype(dtype)          # (B, C, X, Y, Z)
+    base[rng.random(base.shape) < 0.05] = np.nan
+    bd = t(base, dev)
+    for perm in ((0, 2, 3, 4, 1), (1, 0, 2, 3, 4), (4, 3, 2, 1, 0), (0, 1, 3, 2, 4)):
+        x, xd = base.transpose(perm), bd.permute(perm)
+        assert not xd.is_contiguous()
+        x64 = x.astype(np.float64)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for dim in (-1, 0, 2, (1, 2), (1, 2, 3), (0, 4), [3]):
+                ax = tuple(dim) if isinstance(dim, (list, tuple)) else dim
+                e = np.nansum(x64, axis=ax)
+                r = R().nansum(xd, dim=dim, dtype=torch.float64).cpu().numpy()
+                assert r.shape == e.shape and np.abs(r - e).max() <= 1e-12 * np.nansum(np.abs(x64)), (perm, dim)
+                rk = R().nansum(xd, dim=dim, keepdim=True)
+                assert rk.shape == np.nansum(x64, axis=ax, keepdims=True).shape
+                xx = np.where(np.isnan(x), -np.inf, x)
+                assert np.array_equal(R().nanmax(xd, dim=dim).cpu().numpy(), xx.max(axis=ax)), (perm, dim)
+                m = R().nanmean(xd, dim=dim, dtype=torch.float64).cpu().numpy()
+                assert np.nanmax(np.abs(m - np.nanmean(x64, axis=ax)), initial=0) <= 1e-12
+                v = R().nanvar(xd, dim=dim, dtype=torch.float64).cpu().numpy()
+                ev = np.nanvar(x64, axis=ax, ddof=1)
+                ok = np.isfinite(ev)
+                assert np.abs(v[ok] - ev[ok]).max(initial=0) <= 1e-11
+            # indices: scalar dim and a pair of dims
+            v, i = R().nanmax(xd, dim=-1, return_indices=True)
+            assert np.array_equal(i.cpu().numpy(), np.where(np.isnan(x), -np.inf, x).argmax(-1))
+            v, i = R().nanmin(xd, dim=(1, 2), return_indices=True)
+            xx = np.where(np.isnan(x), np.inf, x)
+            sh = x.shape
+            flat = np.moveaxis(xx, (1, 2), (-2, -1)).reshape(sh[0], sh[3], sh[4], -1).argmin(-1)
+            assert np.array_equal(i.cpu().numpy(), np.stack(np.unravel_index(flat, (sh[1], sh[2])), -1)), perm
