@@ -215,23 +215,31 @@ struct TileIO {
 // SoaIO<T, R, Cc, TILE>: component-major ("SoA", channel-first) operands -- element i of
 // component (r, c) at ptr[i + r*sr + c*sc].  Consecutive lanes already touch consecutive
 // addresses, but one element per lane is only a 4-byte access; instead the workgroup
-// streams every component's TILE-element run with 16-byte vectors (1 KiB per wave
-// instruction) into an LDS image laid out [component][TILE], from which lane t reads
-// element t of every component (stride-1 across lanes: conflict-free).
+// streams every component's TILE-element run with ALIGNED 16-byte vectors (1 KiB per wave
+// instruction) into an LDS image laid out [component][TILE + kVec], from which lane t
+// reads element t of every component (stride-1 across lanes: conflict-free).
+// A component run need not start on a 16-byte boundary (volumes with an odd number of
+// voxels never do): the vectors are taken from the aligned address below the run, so the
+// image of component c is shifted by a_c = (address of its first element / sizeof(T)) mod
+// kVec, and only the (at most two) vectors that straddle the ends of the run are handled
+// element by element -- neighbouring tiles own the other halves of those vectors.
 // ---------------------------------------------------------------------------
 template <typename T, int R, int Cc, int TILE>
 struct SoaIO {
     using V = typename VecOf<T>::type;
     static constexpr int kVec = VecOf<T>::N;
     static constexpr int C = R * Cc;
-    static constexpr int kVecPerComp = TILE / kVec;
+    static constexpr int kVecPerComp = TILE / kVec; // + one "extra" vector per shifted component
+    static constexpr int kPitch = TILE + kVec;      // elements per component row in LDS
     static constexpr int kNVec = C * kVecPerComp;
     static constexpr int kIters = (kNVec + TILE - 1) / TILE;
-    static constexpr int kLdsBytes = C * TILE * (int)sizeof(T);
+    static constexpr int kLdsBytes = C * kPitch * (int)sizeof(T);
     static_assert(TILE % kVec == 0, "tile must be a whole number of vectors");
+    static constexpr int kXIters = (C + TILE - 1) / TILE; // extra vectors per lane (1 unless C > TILE)
 
     struct Stage {
         V v[kIters];
+        V x[kXIters]; // the extra vector of component `threadIdx.x` (+ k * TILE): shifted runs only
     };
 
     static __device__ __forceinline__ int64_t comp_off(int comp, int64_t sr, int64_t sc)
@@ -239,72 +247,119 @@ struct SoaIO {
         const int r = comp / Cc, c = comp - r * Cc;
         return r * sr + c * sc;
     }
+    // shift of a component's image: its first element sits `mis` elements above a 16-byte boundary
+    static __device__ __forceinline__ int mis(const T *g, int64_t off)
+    {
+        return (int)(((int64_t)(reinterpret_cast<uintptr_t>(g) / sizeof(T)) + off) & (kVec - 1));
+    }
 
-    // g = address of element tile0 of component (0, 0); left = elements from tile0 to the end
+    // g = address of element tile0 of component (0, 0); left = elements from tile0 to the end.
+    // A vector that holds at least one element of the run is loaded whole: an aligned 16-byte
+    // access cannot leave the page of that element, and the lanes outside the run only land
+    // in image slots that no record reads.
     static __device__ __forceinline__ void issue(const T *__restrict__ g, int64_t sr, int64_t sc, int64_t left,
                                                  Stage &st)
     {
         const int tid = threadIdx.x;
+        const int n = left < TILE ? (int)left : TILE; // elements of this tile
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const int q = tid + it * TILE;
             if (kNVec % TILE == 0 || q < kNVec) {
-                const int comp = q / kVecPerComp, j = (q - comp * kVecPerComp) * kVec;
-                const T *p = g + comp_off(comp, sr, sc) + j;
-                if (j + kVec <= left) {
-                    st.v[it] = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
-                } else {
-                    V v;
-#pragma unroll
-                    for (int k = 0; k < kVec; ++k) v[k] = (j + k < left) ? p[k] : T(1);
-                    st.v[it] = v;
-                }
+                const int comp = q / kVecPerComp, jv = q - comp * kVecPerComp;
+                const int64_t off = comp_off(comp, sr, sc);
+                const int e0 = jv * kVec - mis(g, off); // tile element held by slot 0 of the vector
+                if (e0 + kVec > 0 && e0 < n)
+                    st.v[it] = __builtin_nontemporal_load(reinterpret_cast<const V *>(g + off + e0));
             }
         }
+#pragma unroll
+        for (int k = 0; k < kXIters; ++k) {
+            const int comp = tid + k * TILE;
+            if (comp < C) {
+                const int64_t off = comp_off(comp, sr, sc);
+                const int a = mis(g, off);
+                if (a != 0 && TILE - a < n)
+                    st.x[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(g + off + (TILE - a)));
+            }
+        }
+    }
+
+    static __device__ __forceinline__ int slot(int q) // LDS element index of main vector q
+    {
+        const int comp = q / kVecPerComp, jv = q - comp * kVecPerComp;
+        return comp * kPitch + jv * kVec;
     }
 
     static __device__ __forceinline__ void commit(unsigned char *lds, const Stage &st)
     {
         const int tid = threadIdx.x;
+        T *l = reinterpret_cast<T *>(lds);
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const int q = tid + it * TILE;
-            if (kNVec % TILE == 0 || q < kNVec) *reinterpret_cast<V *>(lds + q * 16) = st.v[it];
+            if (kNVec % TILE == 0 || q < kNVec) *reinterpret_cast<V *>(l + slot(q)) = st.v[it];
+        }
+#pragma unroll
+        for (int k = 0; k < kXIters; ++k) {
+            const int comp = tid + k * TILE;
+            if (comp < C) *reinterpret_cast<V *>(l + comp * kPitch + TILE) = st.x[k];
         }
     }
 
-    static __device__ __forceinline__ void read_own(const unsigned char *lds, T (&r)[C])
+    static __device__ __forceinline__ void read_own(const unsigned char *lds, T (&r)[C], const T *g, int64_t sr,
+                                                    int64_t sc)
     {
         const T *p = reinterpret_cast<const T *>(lds) + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < C; ++c) r[c] = p[c * TILE];
+        for (int c = 0; c < C; ++c) r[c] = p[c * kPitch + mis(g, comp_off(c, sr, sc))];
     }
 
-    static __device__ __forceinline__ void write_own(unsigned char *lds, const T (&r)[C])
+    static __device__ __forceinline__ void write_own(unsigned char *lds, const T (&r)[C], const T *g, int64_t sr,
+                                                     int64_t sc)
     {
         T *p = reinterpret_cast<T *>(lds) + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < C; ++c) p[c * TILE] = r[c];
+        for (int c = 0; c < C; ++c) p[c * kPitch + mis(g, comp_off(c, sr, sc))] = r[c];
+    }
+
+    // whole vectors inside the run are stored whole; the two that straddle its ends are stored
+    // element by element (the other halves belong to the neighbouring tiles)
+    static __device__ __forceinline__ void put(T *p, const V v, int e0, int n)
+    {
+        if (e0 >= 0 && e0 + kVec <= n) {
+            __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+        } else {
+#pragma unroll
+            for (int k = 0; k < kVec; ++k)
+                if (e0 + k >= 0 && e0 + k < n) p[k] = v[k];
+        }
     }
 
     static __device__ __forceinline__ void flush(T *__restrict__ g, int64_t sr, int64_t sc, int64_t left,
                                                  const unsigned char *lds)
     {
         const int tid = threadIdx.x;
+        const int n = left < TILE ? (int)left : TILE;
+        const T *l = reinterpret_cast<const T *>(lds);
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const int q = tid + it * TILE;
             if (kNVec % TILE == 0 || q < kNVec) {
-                const int comp = q / kVecPerComp, j = (q - comp * kVecPerComp) * kVec;
-                T *p = g + comp_off(comp, sr, sc) + j;
-                const V v = *reinterpret_cast<const V *>(lds + q * 16);
-                if (j + kVec <= left) {
-                    __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
-                } else {
+                const int comp = q / kVecPerComp, jv = q - comp * kVecPerComp;
+                const int64_t off = comp_off(comp, sr, sc);
+                const int e0 = jv * kVec - mis(g, off);
+                if (e0 + kVec > 0 && e0 < n) put(g + off + e0, *reinterpret_cast<const V *>(l + slot(q)), e0, n);
+            }
+        }
 #pragma unroll
-                    for (int k = 0; k < kVec; ++k)
-                        if (j + k < left) p[k] = v[k];
-                }
+        for (int k = 0; k < kXIters; ++k) {
+            const int comp = tid + k * TILE;
+            if (comp < C) {
+                const int64_t off = comp_off(comp, sr, sc);
+                const int a = mis(g, off);
+                if (a != 0 && TILE - a < n)
+                    put(g + off + (TILE - a), *reinterpret_cast<const V *>(l + comp * kPitch + TILE), TILE - a, n);
             }
         }
     }
@@ -348,16 +403,12 @@ inline bool vec_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_o
 }
 
 // Can the operand take the component-major tile path?  Unit stride along the inner batch
-// level and every component run (and every outer slab) 16-byte aligned.
+// level is all it takes (component runs may start at any element: SoaIO shifts their image).
 inline bool soa_ok(const nfm_operand *op, int C, int rows, size_t elem)
 {
     if (op->ptr == nullptr || C < 2) return false;
-    const int64_t vec = 16 / (int64_t)elem;
-    if (reinterpret_cast<uintptr_t>(op->ptr) % 16 != 0) return false;
-    if (op->stride_inner != 1) return false;
-    if (op->stride_outer % vec != 0 || op->stride_col % vec != 0) return false;
-    if (rows > 1 && op->stride_row % vec != 0) return false;
-    return true;
+    if (reinterpret_cast<uintptr_t>(op->ptr) % elem != 0) return false;
+    return op->stride_inner == 1;
 }
 
 inline Opnd make_opnd(const nfm_operand *op, int tiled)

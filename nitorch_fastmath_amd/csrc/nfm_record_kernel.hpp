@@ -52,6 +52,9 @@ struct RecIO {
     // region size that fits either LDS image of this operand (AoS-transposed or SoA)
     static constexpr int lds_any = lds > soa_lds ? lds : soa_lds;
     static constexpr int pref = can_vec ? MODE_VEC : (can_tile ? MODE_TILED : MODE_STRIDED);
+    // preferred mode when the caller holds component-major (channel-first) fields: every
+    // multi-component operand through the SoA image, scalars packed
+    static constexpr int pref_soa = can_soa ? MODE_SOA : (R::used && R::C == 1 ? MODE_VEC : MODE_STRIDED);
 };
 
 template <typename T, int C>
@@ -155,15 +158,20 @@ struct op_streams : std::false_type {};
 template <class Op>
 struct op_streams<Op, std::void_t<decltype(Op::kStream)>> : std::bool_constant<Op::kStream> {};
 
-// FAST = every operand is a contiguous batch-major block (the default torch layout):
+// KIND_AOS = every operand is a contiguous batch-major block (the default torch layout):
 // the movement mode of each operand is then a compile-time constant (packed access for
 // 4/8/16-byte records, LDS transpose for the rest), which removes every mode branch and
-// a third of the VGPRs (92 -> 60 on the 4x4 solve, 5 -> 8 waves per SIMD).  FAST = false
-// keeps the wave-uniform run-time modes for SoA / broadcast / strided operands.
-template <typename T, class Op, bool FAST>
+// a third of the VGPRs (92 -> 60 on the 4x4 solve, 5 -> 8 waves per SIMD).
+// KIND_SOA = the same for component-major (channel-first) fields: every multi-component
+// operand through the SoA image.  KIND_ANY keeps the wave-uniform run-time modes for mixed,
+// broadcast and strided operands.
+enum { KIND_ANY = 0, KIND_AOS = 1, KIND_SOA = 2 };
+template <typename T, class Op, int KIND>
 __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, Opnd out, int64_t n_inner,
                                                        typename Op::Params prm)
 {
+    constexpr bool FAST = KIND == KIND_AOS;
+    constexpr bool SFAST = KIND == KIND_SOA;
     using L = RecLayout<T, Op>;
     using RA = typename Op::RA;
     using RB = typename Op::RB;
@@ -187,8 +195,10 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     // LDS regions and movement modes: compile-time constants in the FAST kernel
     constexpr int oA = FAST ? L::offA : L::gA, oB = FAST ? L::offB : L::gB;
     constexpr int oC = FAST ? L::offC : L::gC, oO = FAST ? L::offO : L::gO;
-    const int ma = FAST ? IA::pref : a.tiled, mb = FAST ? IB::pref : b.tiled;
-    const int mc = FAST ? IC::pref : c.tiled, mo = FAST ? IO_::pref : out.tiled;
+    const int ma = FAST ? IA::pref : (SFAST ? IA::pref_soa : a.tiled);
+    const int mb = FAST ? IB::pref : (SFAST ? IB::pref_soa : b.tiled);
+    const int mc = FAST ? IC::pref : (SFAST ? IC::pref_soa : c.tiled);
+    const int mo = FAST ? IO_::pref : (SFAST ? IO_::pref_soa : out.tiled);
     const bool use_c = RC::used && c.ptr != nullptr;
     const bool tA = IA::can_tile && ma == MODE_TILED, tB = IB::can_tile && mb == MODE_TILED;
     const bool tC = IC::can_tile && mc == MODE_TILED && use_c, tO = IO_::can_tile && mo == MODE_TILED;
@@ -257,11 +267,11 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     if constexpr (IC::can_tile)
         if (tC) IC::IO::read_own(smem + oC, rc);
     if constexpr (!FAST && IA::can_soa)
-        if (sA) IA::SO::read_own(smem + oA, ra);
+        if (sA) IA::SO::read_own(smem + oA, ra, reinterpret_cast<const T *>(a.ptr) + o * a.so + tile0, a.sr, a.sc);
     if constexpr (!FAST && IB::can_soa)
-        if (sB) IB::SO::read_own(smem + oB, rb);
+        if (sB) IB::SO::read_own(smem + oB, rb, reinterpret_cast<const T *>(b.ptr) + o * b.so + tile0, b.sr, b.sc);
     if constexpr (!FAST && IC::can_soa)
-        if (sC) IC::SO::read_own(smem + oC, rc);
+        if (sC) IC::SO::read_own(smem + oC, rc, reinterpret_cast<const T *>(c.ptr) + o * c.so + tile0, c.sr, c.sc);
 
     // 4. arithmetic.  Streaming Ops (FAST kernel, tiled output) write their output record
     //    element by element into this lane's slot of the LDS image instead of returning
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     }
     if constexpr (!FAST && IO_::can_soa) {
         if (sO) {
-            IO_::SO::write_own(smem + oO, ro);
+            IO_::SO::write_own(smem + oO, ro, reinterpret_cast<const T *>(out.ptr) + o * out.so + tile0, out.sr, out.sc);
             __syncthreads();
             IO_::SO::flush(reinterpret_cast<T *>(out.ptr) + o * out.so + tile0, out.sr, out.sc, left, smem + oO);
             return;
@@ -349,23 +359,38 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     const size_t lds = any ? (size_t)L::gtotal : 0;
     static bool attr_done = false; // > 64 KiB dynamic LDS needs an opt-in, once per kernel
     if (L::gtotal > 64 * 1024 && !attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, true>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_AOS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-        if constexpr (!FAST_ONLY)
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, false>),
+        if constexpr (!FAST_ONLY) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_ANY>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_SOA>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
+        }
         attr_done = true;
     }
     if (fast) {
-        hipLaunchKernelGGL((rec_kernel<T, Op, true>), grid, block, (size_t)L::total,
+        hipLaunchKernelGGL((rec_kernel<T, Op, KIND_AOS>), grid, block, (size_t)L::total,
                            static_cast<hipStream_t>(stream), make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc),
                            make_opnd(out, mo), n_inner, prm);
     } else {
         if constexpr (FAST_ONLY) return NFM_EFALLBACK;
-        else
-            hipLaunchKernelGGL((rec_kernel<T, Op, false>), grid, block, lds, static_cast<hipStream_t>(stream),
-                               make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc), make_opnd(out, mo), n_inner,
-                               prm);
+        else {
+            // channel-first fields: every used operand in its SoA-preferred mode
+            const bool sfast = (!RA::used || ma == L::A::pref_soa) && (!RB::used || mb == L::B::pref_soa) &&
+                               (!RC::used || c_absent || mc == L::C::pref_soa) && mo == L::O::pref_soa &&
+                               L::A::pref_soa != MODE_STRIDED && L::O::pref_soa != MODE_STRIDED &&
+                               (!RB::used || L::B::pref_soa != MODE_STRIDED) &&
+                               (!RC::used || L::C::pref_soa != MODE_STRIDED);
+            if (sfast)
+                hipLaunchKernelGGL((rec_kernel<T, Op, KIND_SOA>), grid, block, lds,
+                                   static_cast<hipStream_t>(stream), make_opnd(a, ma), make_opnd(b, mb),
+                                   make_opnd(c, mc), make_opnd(out, mo), n_inner, prm);
+            else
+                hipLaunchKernelGGL((rec_kernel<T, Op, KIND_ANY>), grid, block, lds,
+                                   static_cast<hipStream_t>(stream), make_opnd(a, ma), make_opnd(b, mb),
+                                   make_opnd(c, mc), make_opnd(out, mo), n_inner, prm);
+        }
     }
     return launch_status();
 }

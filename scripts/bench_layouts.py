@@ -21,7 +21,7 @@ print('| layout | M | n | ms | solves/s | algorithmic GB/s |')
 print('|---|---|---|---|---|---|')
 for M in (4, 6):
     K = M * (M + 1) // 2
-    n = 1 << 24
+    n = 17_000_000          # not a power of two: component planes 2^k bytes apart camp on one HBM channel
     g = torch.Generator(device=dev).manual_seed(M)
     mat = 0.3 * torch.randn(n, K, device=dev, generator=g) / M
     mat[:, :M] += 2
@@ -30,14 +30,18 @@ for M in (4, 6):
     cases = []
     cases.append(('contiguous AoS', mat, vec, (K + 2 * M) * 4))
     cases.append(('channel-first (SoA) views', mat.T.contiguous().T, vec.T.contiguous().T, (K + 2 * M) * 4))
+    nodd = n - 1
+    mo = torch.empty(K, nodd, device=dev).copy_(mat[:nodd].T).T
+    vo = torch.empty(M, nodd, device=dev).copy_(vec[:nodd].T).T
+    cases.append(('channel-first, odd voxel count (runs start at any alignment)', mo, vo, (K + 2 * M) * 4))
     cases.append(('one matrix, n vectors (broadcast mat)', mat[:1], vec, 2 * M * 4))
     cases.append(('n matrices, one vector (broadcast vec)', mat, vec[:1], (K + M) * 4))
     cases.append(('every other record (batch stride 2)', mat[::2], vec[::2], (K + 2 * M) * 4))
     big = torch.randn(n // 2, K, 2, device=dev, generator=g)
     big[:, :M, 0] += 4
     cases.append(('component stride 2', big[..., 0], vec[:n // 2], (K + 2 * M) * 4))
-    m3 = mat.view(1 << 12, 1 << 12, K)[:, ::2]
-    v3 = vec.view(1 << 12, 1 << 12, M)[:, ::2]
+    m3 = mat.view(4000, 4250, K)[:, ::2]
+    v3 = vec.view(4000, 4250, M)[:, ::2]
     cases.append(('two-level batch (rows of a strided 2-D field)', m3, v3, (K + 2 * M) * 4))
     mis = torch.empty(n * K + 1, device=dev)[1:].view(n, K).copy_(mat)
     cases.append(('base pointer off by 4 bytes', mis, vec, (K + 2 * M) * 4))

@@ -180,13 +180,14 @@ def test_inplace_and_eps_and_dtype(dev, oracle, dn, M):
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 @pytest.mark.parametrize('M', [2, 4, 6, 8])
 def test_component_major_tiles(dev, oracle, dn, M):
-    """16-byte-aligned channel-first fields take the SoA tile path (MODE_SOA): vector loads of
-    every component run through LDS; sizes chosen with full and partial tiles"""
+    """channel-first fields take the SoA tile path (MODE_SOA): aligned vector loads of every
+    component run through LDS; sizes with full and partial tiles, voxel counts that are and
+    are not multiples of 4 (odd volumes: every component run starts at another alignment)"""
     dtype = np.float32 if dn == 'f32' else np.float64
     K = M * (M + 1) // 2
     S = N().sym
     ex = M <= 4
-    for B, X, Y in ((2, 40, 20), (1, 4, 3), (3, 16, 17)):        # X*Y % 4 == 0
+    for B, X, Y in ((2, 40, 20), (1, 4, 3), (3, 16, 17), (2, 7, 9), (1, 33, 31), (3, 5, 5), (1, 1, 3), (2, 1, 1)):
         mat, vec = spd_np(B * X * Y, M, dtype, 77 + M + X)
         ref = oracle.sym_solve(mat, vec).reshape(B, X, Y, M)
         refi = oracle.sym_invert(mat).reshape(B, X, Y, K)
@@ -202,6 +203,15 @@ def test_component_major_tiles(dev, oracle, dn, M):
         S.sym_invert(mat_cf, out=inv_cf)
         check(inv_cf, refi, dn, ex)
         check(S.sym_submatvec(vec_cf, mat_cf, vec_cf), refmv, dn, True)
+        # a window of a larger channel-first buffer: runs start and end inside 16-byte vectors,
+        # and whatever surrounds the window must stay untouched
+        n = B * X * Y
+        if n >= 8:
+            pad = torch.full((M, n + 7), 123.0, dtype=vec_cf.dtype, device=dev)
+            win = pad[:, 3:3 + n].t()
+            S.sym_solve(mat_cf.reshape(n, K), vec_cf.reshape(n, M), out=win)
+            check(win, ref.reshape(n, M), dn, ex)
+            assert bool((pad[:, :3] == 123.0).all()) and bool((pad[:, 3 + n:] == 123.0).all())
         v2 = vec_cf.clone(memory_format=torch.preserve_format)
         S.sym_solve_(mat_cf, v2)                                        # in place on an SoA buffer
         check(v2, ref, dn, ex)
