@@ -1,6 +1,6 @@
 // nfm_record_kernel.hpp -- the one kernel skeleton every lane-per-matrix op uses.
 //
-//   rec_kernel<T, Op, FAST>: up to three input records (A, B, C) and one output record
+//   rec_kernel<T, Op, KIND>: up to three input records (A, B, C) and one output record
 //   per batch element; Op::apply() is the in-register arithmetic.  Each operand
 //   independently takes one of four movement modes (LDS-transposed AoS tile, packed
 //   per-lane access, LDS component-major tile, strided per-lane access); the choice is a
