@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnfm_hip.so')
+LIB_PATH = os.environ.get('NFM_HIP_LIB') or os.path.join(_HERE, 'libnfm_hip.so')   # override: kernel experiments
 
 F32, F64 = 0, 1
 MAT_SYM, MAT_DIAG, MAT_SCAL, MAT_FULL = 0, 1, 2, 3

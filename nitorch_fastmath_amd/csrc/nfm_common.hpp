@@ -23,6 +23,19 @@ namespace nfm {
 
 constexpr int kWave = 64;
 
+// streaming global accesses: every byte is touched once, so loads and stores carry the
+// nontemporal hint (measured: see DESIGN.md section 4); the macros exist for that experiment
+#if defined(NFM_PLAIN_LOADS)
+#define NFM_LDG(p) (*(p))
+#else
+#define NFM_LDG(p) __builtin_nontemporal_load(p)
+#endif
+#if defined(NFM_PLAIN_STORES)
+#define NFM_STG(v, p) (*(p) = (v))
+#else
+#define NFM_STG(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
 // Device-side view of nfm_operand (+ whether it takes the LDS-transposed path).
 struct Opnd {
     char *ptr;
@@ -102,7 +115,7 @@ struct TileIO {
             for (int it = 0; it < kIters; ++it) {
                 const int q = tid + it * TILE;
                 if (kNVec % TILE == 0 || q < kNVec)
-                    st.v[it] = __builtin_nontemporal_load(reinterpret_cast<const V *>(g) + q);
+                    st.v[it] = NFM_LDG(reinterpret_cast<const V *>(g) + q);
             }
         } else {
 #pragma unroll
@@ -191,7 +204,7 @@ struct TileIO {
                 const int q = tid + it * TILE;
                 if (kNVec % TILE == 0 || q < kNVec) {
                     V v = *reinterpret_cast<const V *>(lds + lds_off(q));
-                    __builtin_nontemporal_store(v, reinterpret_cast<V *>(g) + q);
+                    NFM_STG(v, reinterpret_cast<V *>(g) + q);
                 }
             }
         } else {
@@ -270,7 +283,7 @@ struct SoaIO {
                 const int64_t off = comp_off(comp, sr, sc);
                 const int e0 = jv * kVec - mis(g, off); // tile element held by slot 0 of the vector
                 if (e0 + kVec > 0 && e0 < n)
-                    st.v[it] = __builtin_nontemporal_load(reinterpret_cast<const V *>(g + off + e0));
+                    st.v[it] = NFM_LDG(reinterpret_cast<const V *>(g + off + e0));
             }
         }
 #pragma unroll
@@ -280,7 +293,7 @@ struct SoaIO {
                 const int64_t off = comp_off(comp, sr, sc);
                 const int a = mis(g, off);
                 if (a != 0 && TILE - a < n)
-                    st.x[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(g + off + (TILE - a)));
+                    st.x[k] = NFM_LDG(reinterpret_cast<const V *>(g + off + (TILE - a)));
             }
         }
     }
@@ -328,7 +341,7 @@ struct SoaIO {
     static __device__ __forceinline__ void put(T *p, const V v, int e0, int n)
     {
         if (e0 >= 0 && e0 + kVec <= n) {
-            __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+            NFM_STG(v, reinterpret_cast<V *>(p));
         } else {
 #pragma unroll
             for (int k = 0; k < kVec; ++k)

@@ -72,7 +72,7 @@ __device__ __forceinline__ void rec_vec_load(const Opnd &op, int64_t o, int64_t 
     using P = typename PackOf<T, R::Cs>::type;
     const P *p = reinterpret_cast<const P *>(reinterpret_cast<const T *>(op.ptr) + o * op.so + i * R::Cs);
     if (valid) {
-        const P v = __builtin_nontemporal_load(p);
+        const P v = NFM_LDG(p);
         if constexpr (R::Cs == 1) r[0] = v;
         else {
 #pragma unroll
@@ -97,7 +97,7 @@ __device__ __forceinline__ void rec_vec_store(const Opnd &op, int64_t o, int64_t
 #pragma unroll
             for (int c = 0; c < R::Cs; ++c) v[c] = r[c];
         }
-        __builtin_nontemporal_store(v, p);
+        NFM_STG(v, p);
     }
 }
 
