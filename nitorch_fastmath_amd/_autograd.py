@@ -3,9 +3,11 @@ HIP kernels of libnfm_hip.so (the backward of a solve is a solve, of a mat-vec a
 plus one `nfm_sym_outer2` launch for the compact-matrix cotangent).  Element-wise glue in
 the backward of the reductions (mask, broadcast, divide) is plain torch on the device.
 
-Covered: sym_matvec / sym_addmatvec / sym_submatvec, sym_solve, eig_sym (eigenvalues, and
-eigenvectors through Giles' formula, as upstream's `_EigSym` `_impl/qr.py:684-735` intends),
-sum / nansum / mean / nanmean.  Everything else is forward-only and says so.
+Covered: sym_matvec / sym_addmatvec / sym_submatvec, sym_solve, sym_invert (+ diag), sym_det,
+batchmatvec / batchinv / batchdet, eig_sym (eigenvalues, and eigenvectors through Giles' formula,
+as upstream's `_EigSym` `_impl/qr.py:684-735` intends), sum / nansum / mean / nanmean,
+max / min / nanmax / nanmin (the cotangent goes to the selected element), var / std / nanvar /
+nanstd.  Everything else is forward-only and says so.
 """
 import ctypes
 import torch
@@ -209,3 +211,237 @@ class SumFn(torch.autograd.Function):
         if omitnan:
             g = torch.where(torch.isnan(x), torch.zeros_like(g), g)
         return g.to(ctx.in_dtype), None, None, None, None, None
+
+
+# ---------------------------------------------------------------- batched / sym inverses, dets
+def _unsq(g, nd_out, dims, keepdim):
+    if not keepdim:
+        for d in sorted(dims):
+            g = g.unsqueeze(d)
+    return g
+
+
+class BatchMatvecFn(torch.autograd.Function):
+    """y = A v:  dA = g v^T (broadcast product),  dv = A^T g (the same kernel on the transposed view)."""
+
+    @staticmethod
+    def forward(ctx, mat, vec):
+        from . import batched as B
+        ctx.save_for_backward(mat, vec)
+        with torch.no_grad():
+            return B.batchmatvec(mat, vec)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import batched as B
+        mat, vec = ctx.saved_tensors
+        gm = gv = None
+        if ctx.needs_input_grad[0]:
+            gm = _sum_to(g.unsqueeze(-1) * vec.unsqueeze(-2), mat.shape).to(mat.dtype)
+        if ctx.needs_input_grad[1]:
+            gv = _sum_to(B.batchmatvec(mat.transpose(-1, -2), g), vec.shape).to(vec.dtype)
+        return gm, gv
+
+
+class BatchInvFn(torch.autograd.Function):
+    """B = A^-1:  dA = -B^T G B^T."""
+
+    @staticmethod
+    def forward(ctx, a, perturb):
+        from . import batched as B
+        with torch.no_grad():
+            inv = B.batchinv(a, perturb=perturb)
+        ctx.save_for_backward(inv)
+        return inv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        it = inv.transpose(-1, -2)
+        return -_small_matmul(_small_matmul(it, g), it), None
+
+
+class BatchDetFn(torch.autograd.Function):
+    """d = det A:  dA = g d A^-T (one inverse kernel)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        from . import batched as B
+        with torch.no_grad():
+            d = B.batchdet(a)
+        ctx.save_for_backward(a, d)
+        return d
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import batched as B
+        a, d = ctx.saved_tensors
+        return (g * d).unsqueeze(-1).unsqueeze(-1) * B.batchinv(a).transpose(-1, -2)
+
+
+def _full_to_compact_grad(gf):
+    """pull a full-matrix cotangent (..., M, M) back onto compact storage: g_ii, g_ij + g_ji."""
+    M = gf.shape[-1]
+    parts = [gf.diagonal(dim1=-2, dim2=-1)]
+    s = gf + gf.transpose(-1, -2)
+    for i in range(M):
+        if i + 1 < M:
+            parts.append(s[..., i, i + 1:])
+    return torch.cat(parts, -1)
+
+
+class SymInvertFn(torch.autograd.Function):
+    """compact B = A^-1 (or its diagonal): full cotangent -B G B pulled back onto compact storage."""
+
+    @staticmethod
+    def forward(ctx, mat, diag, dtype):
+        from . import sym as S
+        with torch.no_grad():
+            inv = S.sym_invert(mat, dtype=dtype)
+        ctx.save_for_backward(inv)
+        ctx.diag = diag
+        ctx.in_dtype = mat.dtype
+        M = S._nb_prm(mat.shape[-1])
+        return inv[..., :M].clone() if diag else inv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import sym as S
+        (inv,) = ctx.saved_tensors
+        Bf = S.sym_to_full(inv)
+        Gf = torch.diag_embed(g) if ctx.diag else S.sym_to_full(g)
+        if not ctx.diag:
+            # the compact cotangent counts an off-diagonal entry once: split it over (i, j) and (j, i)
+            Gf = (Gf + torch.diag_embed(Gf.diagonal(dim1=-2, dim2=-1))) / 2
+        full = -_small_matmul(_small_matmul(Bf, Gf), Bf)
+        return _full_to_compact_grad(full).to(ctx.in_dtype), None, None
+
+
+class SymDetFn(torch.autograd.Function):
+    """d = det A (compact):  full cotangent g d A^-1 pulled back onto compact storage."""
+
+    @staticmethod
+    def forward(ctx, mat, dtype):
+        from . import sym as S
+        with torch.no_grad():
+            d = S.sym_det(mat, dtype=dtype)
+        ctx.save_for_backward(mat, d)
+        ctx.in_dtype = mat.dtype
+        return d
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import sym as S
+        mat, d = ctx.saved_tensors
+        inv = S.sym_invert(mat, dtype=d.dtype)          # compact A^-1
+        M = S._nb_prm(mat.shape[-1])
+        scale = torch.cat([torch.ones(M, dtype=d.dtype, device=d.device),
+                           torch.full((inv.shape[-1] - M,), 2.0, dtype=d.dtype, device=d.device)])
+        return ((g * d).unsqueeze(-1) * inv * scale).to(ctx.in_dtype), None
+
+
+# ---------------------------------------------------------------- max / min, var / std
+class PickFn(torch.autograd.Function):
+    """max / min / nanmax / nanmin over dims: the cotangent goes to the selected element."""
+
+    @staticmethod
+    def forward(ctx, input, which, dim, keepdim, omitnan):
+        from . import reduce as R
+        fn = R.max if which == 'max' else R.min
+        with torch.no_grad():
+            if dim is None:
+                flat = input.reshape(-1)
+                val, idx = fn(flat, dim=0, omitnan=omitnan, return_indices=True)
+                ctx.cfg = (None, keepdim, tuple(input.shape))
+            else:
+                val, idx = fn(input, dim=dim, keepdim=True, omitnan=omitnan, return_indices=True)
+                ctx.cfg = (dim, keepdim, tuple(input.shape))
+        ctx.save_for_backward(idx)
+        ctx.in_dtype = input.dtype
+        if dim is None:
+            return val.reshape([1] * input.dim()) if keepdim else val
+        if keepdim:
+            return val
+        nd = input.dim()
+        from .utils import ensure_list
+        dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
+        return val.squeeze(tuple(dims))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from .utils import ensure_list
+        (idx,) = ctx.saved_tensors
+        dim, keepdim, shape = ctx.cfg
+        nd = len(shape)
+        if dim is None:
+            out = torch.zeros(shape, dtype=g.dtype, device=g.device)
+            out.view(-1)[idx] = g.reshape(())
+            return out.to(ctx.in_dtype), None, None, None, None
+        dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
+        g = g if keepdim else _unsq(g, nd, dims, False)
+        scalar = not isinstance(dim, (list, tuple, range))
+        sub = idx.unsqueeze(-1) if scalar else idx          # (keptshape..., len(dims))
+        out = torch.zeros(shape, dtype=g.dtype, device=g.device)
+        grids = torch.meshgrid(*[torch.arange(1 if d in dims else s, device=g.device) for d, s in enumerate(shape)],
+                               indexing='ij')
+        index = [sub[..., dims.index(d)] if d in dims else grids[d] for d in range(nd)]
+        out.index_put_(tuple(index), g.expand(sub.shape[:-1]), accumulate=True)
+        return out.to(ctx.in_dtype), None, None, None, None
+
+
+class VarFn(torch.autograd.Function):
+    """var / std (+ nan variants): d/dx = 2 (x - mean) / (n - ddof) [/ (2 std)] on the counted elements."""
+
+    @staticmethod
+    def forward(ctx, input, dim, keepdim, unbiased, omitnan, std, dtype):
+        from . import reduce as R
+        with torch.no_grad():
+            fn = R.std if std else R.var
+            out = fn(input, dim, True, unbiased, omitnan, dtype=torch.float64)
+            mean = R.mean(input, dim, True, omitnan, dtype=torch.float64)
+            if omitnan:
+                cnt = R._reduce(_lib.RED_NANCOUNT, input, dim, True, torch.float64)[0]
+            else:
+                cnt = None
+        ctx.save_for_backward(input, out, mean, cnt if cnt is not None else out)
+        ctx.cfg = (dim, keepdim, unbiased, omitnan, std, cnt is not None)
+        odt = dtype or input.dtype
+        res = out.to(odt)
+        if keepdim:
+            return res
+        nd = input.dim()
+        from .utils import ensure_list
+        dims = list(range(nd)) if dim is None else [d if d >= 0 else nd + d for d in ensure_list(dim)]
+        return res.squeeze(tuple(dims)) if dims else res
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from .utils import ensure_list
+        x, out, mean, cnt = ctx.saved_tensors
+        dim, keepdim, unbiased, omitnan, std, has_cnt = ctx.cfg
+        nd = x.dim()
+        dims = list(range(nd)) if dim is None else [d if d >= 0 else nd + d for d in ensure_list(dim)]
+        g = g.to(torch.float64)
+        if not keepdim:
+            g = _unsq(g, nd, dims, False)
+        if has_cnt:
+            n = cnt
+        else:
+            n = 1
+            for d in dims:
+                n *= x.shape[d]
+        den = n - (1 if unbiased else 0)
+        gx = 2.0 * (x.to(torch.float64) - mean) / den
+        if std:
+            gx = gx / (2.0 * out)
+        gx = gx * g
+        if omitnan:
+            gx = torch.where(torch.isnan(x), torch.zeros_like(gx), gx)
+        return gx.to(x.dtype), None, None, None, None, None, None

@@ -30,6 +30,9 @@ def batchdet(a):
 
     a : `(..., n, n) tensor` -> `(...) tensor`.  Replaces `_impl/batched.py:35-63`.
     """
+    from ._autograd import BatchDetFn, needs_grad
+    if needs_grad(a):
+        return BatchDetFn.apply(torch.as_tensor(a))
     dev, dtype, (a,) = _prep(a)
     n = a.shape[-1]
     assert a.shape[-2] == n, 'Expected square matrices'
@@ -54,6 +57,9 @@ def batchinv(a, perturb=False):
         determinant perturbation `(max|a| - min|a|) * 1e-12` (`_impl/batched.py:74-76`).
         The default matches the reference's CPU path (`a.inverse()`).
     """
+    from ._autograd import BatchInvFn, needs_grad
+    if needs_grad(a):
+        return BatchInvFn.apply(torch.as_tensor(a), bool(perturb))
     dev, dtype, (a,) = _prep(a)
     n = a.shape[-1]
     assert a.shape[-2] == n, 'Expected square matrices'
@@ -74,6 +80,9 @@ def batchmatvec(mat, vec):
 
     mat : `(..., m, n)`, vec : `(..., n)` -> `(..., m)`.  Replaces `_impl/batched.py:154-190`.
     """
+    from ._autograd import BatchMatvecFn, needs_grad
+    if needs_grad(mat, vec):
+        return BatchMatvecFn.apply(torch.as_tensor(mat), torch.as_tensor(vec))
     dev, dtype, (mat, vec) = _prep(mat, vec)
     m, n = mat.shape[-2:]
     if vec.shape[-1] != n:

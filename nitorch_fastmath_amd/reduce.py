@@ -232,17 +232,35 @@ def _reduce_index(op_plain, op_nan, input, dim, keepdim, omitnan, return_indices
     return val, _deliver(sub, out_ind)
 
 
+def _pick_with_grad(which, input, dim, keepdim, omitnan, return_indices, out):
+    """differentiable max / min: values through `PickFn`, indices (no gradient) on the side"""
+    from ._autograd import PickFn
+    if out is not None:
+        raise RuntimeError('out= is not supported for tensors that require grad')
+    input = torch.as_tensor(input)
+    val = PickFn.apply(input, which, dim, keepdim, omitnan)
+    if not return_indices or dim is None:
+        return val
+    with torch.no_grad():
+        _, idx = (max if which == 'max' else min)(input.detach(), dim, keepdim, omitnan, False, True)
+    return val, idx
+
+
 def max(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_indices=False, out=None):
     r"""Multi-dimensional max reduction (`reduce.py:145-197`).
 
     max(input) -> Tensor; max(input, dim) -> Tensor;
     max(input, dim, return_indices=True) -> (Tensor, Tensor)
     """
+    if _needs_grad(torch.as_tensor(input)):
+        return _pick_with_grad('max', input, dim, keepdim, omitnan, return_indices, out)
     return _reduce_index(_lib.RED_MAX, _lib.RED_NANMAX, input, dim, keepdim, omitnan, return_indices, out)
 
 
 def min(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_indices=False, out=None):
     r"""Multi-dimensional min reduction (`reduce.py:200-252`)."""
+    if _needs_grad(torch.as_tensor(input)):
+        return _pick_with_grad('min', input, dim, keepdim, omitnan, return_indices, out)
     return _reduce_index(_lib.RED_MIN, _lib.RED_NANMIN, input, dim, keepdim, omitnan, return_indices, out)
 
 
@@ -409,6 +427,9 @@ def nanmean(input, dim=None, keepdim=False, inplace=False, dtype=None, out=None)
 def var(input, dim=None, keepdim=False, unbiased=True, omitnan=False, inplace=False, dtype=None, out=None):
     """Variance of a tensor (`reduce.py:597-635`; the non-NaN form raises upstream, quirk Q13)."""
     input = torch.as_tensor(input)
+    if _needs_grad(input):
+        from ._autograd import VarFn
+        return _deliver(VarFn.apply(input, dim, keepdim, unbiased, omitnan, False, dtype), out)
     return _deliver(_stat(_STAT_VAR, input, dim, keepdim, omitnan, unbiased, dtype or input.dtype), out)
 
 
@@ -420,6 +441,9 @@ def nanvar(input, dim=None, keepdim=False, unbiased=True, inplace=False, dtype=N
 def std(input, dim=None, keepdim=False, unbiased=True, omitnan=False, inplace=False, dtype=None, out=None):
     """Standard deviation of a tensor (`reduce.py:688-726`)."""
     input = torch.as_tensor(input)
+    if _needs_grad(input):
+        from ._autograd import VarFn
+        return _deliver(VarFn.apply(input, dim, keepdim, unbiased, omitnan, True, dtype), out)
     return _deliver(_stat(_STAT_STD, input, dim, keepdim, omitnan, unbiased, dtype or input.dtype), out)
 
 

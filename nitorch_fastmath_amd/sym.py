@@ -239,6 +239,11 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
     diag : `bool`, default=False
         If True, only return the diagonal of the inverse, shape `(..., M)`.
     """
+    from ._autograd import SymInvertFn, needs_grad
+    if needs_grad(mat):
+        if out is not None:
+            raise RuntimeError('out= is not supported for tensors that require grad')
+        return SymInvertFn.apply(torch.as_tensor(mat), bool(diag), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])
     _check_order(M)
@@ -265,6 +270,11 @@ def sym_det(mat, dtype=None, out=None):
     The reference derives M from a batch dimension by mistake (quirk Q2); this
     implementation uses the compact dimension, as documented.
     """
+    from ._autograd import SymDetFn, needs_grad
+    if needs_grad(mat):
+        if out is not None:
+            raise RuntimeError('out= is not supported for tensors that require grad')
+        return SymDetFn.apply(torch.as_tensor(mat), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])
     _check_order(M)

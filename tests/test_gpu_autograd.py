@@ -92,7 +92,7 @@ def test_sym_solve_backward_broadcast_and_kinds(dev):
     with pytest.raises(RuntimeError, match='out='):
         N().sym_solve(md, vd, out=torch.empty(n, M, dtype=torch.float64, device=dev))
     with pytest.raises(NotImplementedError):
-        N().sym_invert(md)
+        N().sym_outer(vd)          # still forward-only
 
 
 @pytest.mark.parametrize('n', [2, 3, 4, 6])
@@ -162,4 +162,103 @@ def test_reduce_backward(dev):
     R.mean(yd).backward()
     assert torch.allclose(yd.grad.cpu(), yc.grad)
     with pytest.raises(NotImplementedError):
-        R.nanmax(yd, dim=1)
+        R.median(yd, dim=1) if False else N().qr.hessenberg(torch.randn(3, 3, device=dev, requires_grad=True))
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 6])
+def test_batched_backward(dev, n):
+    """batchmatvec / batchinv / batchdet against torch's autograd of the dense fp64 ops on the CPU"""
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(7, n, n, dtype=torch.float64, generator=g) + 4 * torch.eye(n, dtype=torch.float64)
+    v = torch.randn(7, n, dtype=torch.float64, generator=g)
+    w = torch.randn(7, n, n, dtype=torch.float64, generator=g)
+    B = N().batched
+    ac, vc = a.clone().requires_grad_(), v.clone().requires_grad_()
+    ad, vd = a.to(dev).requires_grad_(), v.to(dev).requires_grad_()
+    (torch.matmul(ac, vc.unsqueeze(-1)).squeeze(-1) * w[:, 0]).sum().backward()
+    (B.batchmatvec(ad, vd) * w[:, 0].to(dev)).sum().backward()
+    assert torch.allclose(ad.grad.cpu(), ac.grad, rtol=1e-11, atol=1e-12)
+    assert torch.allclose(vd.grad.cpu(), vc.grad, rtol=1e-11, atol=1e-12)
+    # broadcast vector: one vector for every matrix
+    v1c, v1d = v[0].clone().requires_grad_(), v[0].to(dev).requires_grad_()
+    (torch.matmul(a, v1c) * w[:, 0]).sum().backward()
+    (B.batchmatvec(a.to(dev), v1d) * w[:, 0].to(dev)).sum().backward()
+    assert torch.allclose(v1d.grad.cpu(), v1c.grad, rtol=1e-11, atol=1e-12)
+    for ours, ref, wt in ((B.batchinv, torch.linalg.inv, w), (B.batchdet, torch.linalg.det, w[:, 0, 0])):
+        ac, ad = a.clone().requires_grad_(), a.to(dev).requires_grad_()
+        (ref(ac) * wt).sum().backward()
+        (ours(ad) * wt.to(dev)).sum().backward()
+        assert torch.allclose(ad.grad.cpu(), ac.grad, rtol=1e-9, atol=1e-10), ours.__name__
+
+
+@pytest.mark.parametrize('M', [1, 2, 3, 4, 6])
+def test_sym_invert_and_det_backward(dev, M):
+    mat, v, w = spd(9, M, 40 + M)
+    S = N().sym
+    K = M * (M + 1) // 2
+    wk = torch.randn(9, K, dtype=torch.float64, generator=torch.Generator().manual_seed(M))
+
+    def compact(full):
+        cols = [full[..., i, i] for i in range(M)] + [full[..., i, j] for i in range(M) for j in range(i + 1, M)]
+        return torch.stack(cols, -1)
+    mc, md = mat.clone().requires_grad_(), mat.to(dev).requires_grad_()
+    (compact(torch.linalg.inv(to_full(mc, M))) * wk).sum().backward()
+    (S.sym_invert(md) * wk.to(dev)).sum().backward()
+    assert torch.allclose(md.grad.cpu(), mc.grad, rtol=1e-9, atol=1e-10)
+    mc, md = mat.clone().requires_grad_(), mat.to(dev).requires_grad_()
+    (torch.linalg.inv(to_full(mc, M)).diagonal(dim1=-2, dim2=-1) * w).sum().backward()
+    (S.sym_invert(md, diag=True) * w.to(dev)).sum().backward()
+    assert torch.allclose(md.grad.cpu(), mc.grad, rtol=1e-9, atol=1e-10)
+    mc, md = mat.clone().requires_grad_(), mat.to(dev).requires_grad_()
+    (torch.linalg.det(to_full(mc, M)) * w[:, 0]).sum().backward()
+    (S.sym_det(md) * w[:, 0].to(dev)).sum().backward()
+    assert torch.allclose(md.grad.cpu(), mc.grad, rtol=1e-9, atol=1e-10)
+
+
+def test_pick_and_var_backward(dev):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 9, 5, dtype=torch.float64, generator=g)
+    R = N().reduce
+    w = torch.randn(4, 5, dtype=torch.float64, generator=g)
+    for name, ref in (('max', lambda t: t.amax(1)), ('min', lambda t: t.amin(1))):
+        xc, xd = x.clone().requires_grad_(), x.to(dev).requires_grad_()
+        (ref(xc) * w).sum().backward()
+        (getattr(R, name)(xd, dim=1) * w.to(dev)).sum().backward()
+        assert torch.equal(xd.grad.cpu(), xc.grad), name
+        xc, xd = x.clone().requires_grad_(), x.to(dev).requires_grad_()
+        ref(xc).sum().backward()
+        val, idx = getattr(R, name)(xd, dim=1, keepdim=True, return_indices=True)
+        val.sum().backward()
+        assert val.shape == (4, 1, 5) and torch.equal(xd.grad.cpu(), xc.grad)
+    # several dims, NaNs skipped, full reduction
+    xn = x.clone()
+    xn[torch.rand(xn.shape, generator=g) < 0.2] = float('nan')
+    xc, xd = xn.clone().requires_grad_(), xn.to(dev).requires_grad_()
+    torch.nan_to_num(xc, nan=-float('inf')).amax((0, 2)).sum().backward()
+    R.nanmax(xd, dim=(0, 2)).sum().backward()
+    assert torch.equal(xd.grad.cpu(), xc.grad)
+    xc, xd = x.clone().requires_grad_(), x.to(dev).requires_grad_()
+    (xc.max() * 2).backward()
+    (R.max(xd) * 2).backward()
+    assert torch.equal(xd.grad.cpu(), xc.grad)
+    # var / std, biased and unbiased, one and several dims
+    for dim in (1, (0, 2), None):
+        for unb in (True, False):
+            for ours, ref in ((R.var, torch.var), (R.std, torch.std)):
+                xc, xd = x.clone().requires_grad_(), x.to(dev).requires_grad_()
+                kw = {} if dim is None else {'dim': dim}
+                r = ref(xc, unbiased=unb, **kw)
+                o = ours(xd, dim=dim, unbiased=unb)
+                assert torch.allclose(o.detach().cpu(), r.detach(), rtol=1e-12)
+                (r ** 2).sum().backward()
+                (o ** 2).sum().backward()
+                assert torch.allclose(xd.grad.cpu(), xc.grad, rtol=1e-10, atol=1e-12), (dim, unb, ours.__name__)
+    # nanvar: gradient only on the counted elements
+    xd = xn.to(dev).requires_grad_()
+    R.nanvar(xd, dim=1).sum().backward()
+    mask = (~torch.isnan(xn)).double()
+    xc = torch.nan_to_num(xn).requires_grad_()           # NaN-free leaf: masked arithmetic instead
+    cnt = mask.sum(1, keepdim=True)
+    mean = (xc * mask).sum(1, keepdim=True) / cnt
+    ((((xc - mean) ** 2) * mask).sum(1) / (cnt.squeeze(1) - 1)).sum().backward()
+    assert torch.allclose(xd.grad.cpu(), xc.grad * mask, rtol=1e-10, atol=1e-12)
