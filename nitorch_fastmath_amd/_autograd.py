@@ -4,6 +4,7 @@ plus one `nfm_sym_outer2` launch for the compact-matrix cotangent).  Element-wis
 the backward of the reductions (mask, broadcast, divide) is plain torch on the device.
 
 Covered: sym_matvec / sym_addmatvec / sym_submatvec, sym_solve, sym_invert (+ diag), sym_det,
+sym_to_full, sym_outer, sym_matmul,
 batchmatvec / batchinv / batchdet, eig_sym (eigenvalues, and eigenvectors through Giles' formula,
 as upstream's `_EigSym` `_impl/qr.py:684-735` intends), sum / nansum / mean / nanmean,
 max / min / nanmax / nanmin (the cotangent goes to the selected element), var / std / nanvar /
@@ -159,11 +160,11 @@ class EigSymFn(torch.autograd.Function):
 
 
 def _small_matmul(a, b):
-    """(..., n, n) @ (..., n, n) for tiny n as broadcast multiply-adds (rocBLAS batched GEMM is
+    """(..., n, m) @ (..., m, p) for tiny sizes as broadcast multiply-adds (rocBLAS batched GEMM is
     slow, and faults, on batches of ~1e7 tiny matrices)."""
-    n = a.shape[-1]
+    m = a.shape[-1]
     out = a[..., :, 0:1] * b[..., 0:1, :]
-    for k in range(1, n):
+    for k in range(1, m):
         out = out + a[..., :, k:k + 1] * b[..., k:k + 1, :]
     return out
 
@@ -445,3 +446,85 @@ class VarFn(torch.autograd.Function):
         if omitnan:
             gx = torch.where(torch.isnan(x), torch.zeros_like(gx), gx)
         return gx.to(x.dtype), None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------- sym_to_full / sym_outer / sym_matmul
+def _halved_full(g):
+    """full symmetric matrix G with <G, full(c)> = <g, c> for every compact c: off-diagonals halved"""
+    from . import sym as S
+    Gf = S.sym_to_full(g)
+    return (Gf + torch.diag_embed(Gf.diagonal(dim1=-2, dim2=-1))) / 2
+
+
+class SymToFullFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mat, dtype):
+        from . import sym as S
+        ctx.in_dtype = mat.dtype
+        with torch.no_grad():
+            return S.sym_to_full(mat, dtype=dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return _full_to_compact_grad(g).to(ctx.in_dtype), None
+
+
+class SymOuterFn(torch.autograd.Function):
+    """compact(x x^T): dx_i = 2 g_ii x_i + sum_{j != i} g_ij x_j = one compact mat-vec."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        from . import sym as S
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return S.sym_outer(x, dtype=dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import sym as S
+        (x,) = ctx.saved_tensors
+        M = x.shape[-1]
+        g2 = torch.cat([2 * g[..., :M], g[..., M:]], -1)
+        return S.sym_matvec(g2, x.to(g.dtype)).to(x.dtype), None
+
+
+class SymMatmulFn(torch.autograd.Function):
+    """J^T H J (or J H J^T where the reference computes that, quirk Q16), compact H and output."""
+
+    @staticmethod
+    def forward(ctx, j, h, dtype):
+        from . import sym as S
+        k, d = j.shape[-2:]
+        ctx.sym = h.shape[-1] == k * (k + 1) // 2
+        ctx.flip = ctx.sym and k == d and k in (2, 3)
+        ctx.save_for_backward(j, h)
+        with torch.no_grad():
+            return S.sym_matmul(j, h, dtype=dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import sym as S
+        j, h = ctx.saved_tensors
+        Gf = _halved_full(g)
+        J = j.to(g.dtype)
+        Hf = S.sym_to_full(h.to(g.dtype)) if ctx.sym else torch.diag_embed(h.to(g.dtype))
+        gj = gh = None
+        if ctx.flip:     # out = J H J^T
+            if ctx.needs_input_grad[0]:
+                gj = 2 * _small_matmul(_small_matmul(Gf, J), Hf)
+            if ctx.needs_input_grad[1]:
+                gh = _small_matmul(_small_matmul(J.transpose(-1, -2), Gf), J)
+        else:            # out = J^T H J
+            if ctx.needs_input_grad[0]:
+                gj = 2 * _small_matmul(_small_matmul(Hf, J), Gf)
+            if ctx.needs_input_grad[1]:
+                gh = _small_matmul(_small_matmul(J, Gf), J.transpose(-1, -2))
+        if gh is not None:
+            gh = _full_to_compact_grad(gh) if ctx.sym else gh.diagonal(dim1=-2, dim2=-1)
+            gh = _sum_to(gh, h.shape).to(h.dtype)
+        if gj is not None:
+            gj = _sum_to(gj, j.shape).to(j.dtype)
+        return gj, gh, None

@@ -290,8 +290,17 @@ def sym_det(mat, dtype=None, out=None):
     return out
 
 
+def _grad_guard(out):
+    if out is not None:
+        raise RuntimeError('out= is not supported for tensors that require grad')
+
+
 def sym_to_full(mat, dtype=None, out=None):
     r"""Compact symmetric `(..., M*(M+1)//2)` -> full `(..., M, M)` (`_impl/sym.py:16-60`)."""
+    from ._autograd import SymToFullFn, needs_grad
+    if needs_grad(mat):
+        _grad_guard(out)
+        return SymToFullFn.apply(torch.as_tensor(mat), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])
     _check_order(M)
@@ -316,6 +325,10 @@ def sym_diag(mat):
 
 def sym_outer(x, dtype=None, out=None):
     r"""Symmetric outer product `x x^T` in compact storage (`_impl/sym.py:496-528`)."""
+    from ._autograd import SymOuterFn, needs_grad
+    if needs_grad(x):
+        _grad_guard(out)
+        return SymOuterFn.apply(torch.as_tensor(x), dtype)
     dev, dtype, (x,) = _prep(dtype, x)
     M = x.shape[-1]
     _check_order(M)
@@ -338,6 +351,10 @@ def sym_matmul(j, h, dtype=None, out=None):
     For `k == d` in `{2, 3}` the reference's specialised kernels evaluate `J H J^T`
     (quirk Q16); this function returns what the reference returns.
     """
+    from ._autograd import SymMatmulFn, needs_grad
+    if needs_grad(j, h):
+        _grad_guard(out)
+        return SymMatmulFn.apply(torch.as_tensor(j), torch.as_tensor(h), dtype)
     dev, dtype, (j, h) = _prep(dtype, j, h)
     k, d = j.shape[-2:]
     _check_order(k)

@@ -92,7 +92,7 @@ def test_sym_solve_backward_broadcast_and_kinds(dev):
     with pytest.raises(RuntimeError, match='out='):
         N().sym_solve(md, vd, out=torch.empty(n, M, dtype=torch.float64, device=dev))
     with pytest.raises(NotImplementedError):
-        N().sym_outer(vd)          # still forward-only
+        N().qr.householder(vd)     # still forward-only
 
 
 @pytest.mark.parametrize('n', [2, 3, 4, 6])
@@ -262,3 +262,50 @@ def test_pick_and_var_backward(dev):
     mean = (xc * mask).sum(1, keepdim=True) / cnt
     ((((xc - mean) ** 2) * mask).sum(1) / (cnt.squeeze(1) - 1)).sum().backward()
     assert torch.allclose(xd.grad.cpu(), xc.grad * mask, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('M', [1, 2, 3, 4, 5])
+def test_sym_to_full_outer_matmul_backward(dev, M):
+    mat, v, w = spd(6, M, 70 + M)
+    S = N().sym
+    g = torch.Generator().manual_seed(M)
+    wf = torch.randn(6, M, M, dtype=torch.float64, generator=g)
+    K = M * (M + 1) // 2
+    wk = torch.randn(6, K, dtype=torch.float64, generator=g)
+
+    def compact(full, n):
+        cols = [full[..., i, i] for i in range(n)] + [full[..., i, j] for i in range(n) for j in range(i + 1, n)]
+        return torch.stack(cols, -1)
+    mc, md = mat.clone().requires_grad_(), mat.to(dev).requires_grad_()
+    (to_full(mc, M) * wf).sum().backward()
+    (S.sym_to_full(md) * wf.to(dev)).sum().backward()
+    assert torch.allclose(md.grad.cpu(), mc.grad, rtol=1e-12, atol=1e-13)
+    vc, vd = v.clone().requires_grad_(), v.to(dev).requires_grad_()
+    (compact(vc.unsqueeze(-1) * vc.unsqueeze(-2), M) * wk).sum().backward()
+    (S.sym_outer(vd) * wk.to(dev)).sum().backward()
+    assert torch.allclose(vd.grad.cpu(), vc.grad, rtol=1e-12, atol=1e-13)
+    for d in (1, 2, 3, 4):
+        if M > 4:
+            continue
+        J = torch.randn(6, M, d, dtype=torch.float64, generator=g)
+        Kd = d * (d + 1) // 2
+        wd = torch.randn(6, Kd, dtype=torch.float64, generator=g)
+        flip = M == d and M in (2, 3)                        # quirk Q16: the reference computes J H J^T
+        jc, hc = J.clone().requires_grad_(), mat.clone().requires_grad_()
+        jd, hd = J.to(dev).requires_grad_(), mat.to(dev).requires_grad_()
+        Hf = to_full(hc, M)
+        full = jc @ Hf @ jc.transpose(-1, -2) if flip else jc.transpose(-1, -2) @ Hf @ jc
+        (compact(full, d) * wd).sum().backward()
+        out = S.sym_matmul(jd, hd)
+        assert torch.allclose(out.detach().cpu(), compact(full, d).detach(), rtol=1e-12, atol=1e-12)
+        (out * wd.to(dev)).sum().backward()
+        assert torch.allclose(jd.grad.cpu(), jc.grad, rtol=1e-10, atol=1e-11), (M, d)
+        assert torch.allclose(hd.grad.cpu(), hc.grad, rtol=1e-10, atol=1e-11), (M, d)
+        # diagonal hessian, one hessian for every jacobian (broadcast)
+        dc, dd = mat[0, :M].clone().requires_grad_(), mat[0, :M].to(dev).requires_grad_()
+        jc, jd = J.clone().requires_grad_(), J.to(dev).requires_grad_()
+        (compact(jc.transpose(-1, -2) @ torch.diag_embed(dc) @ jc, d) * wd).sum().backward()
+        (S.sym_matmul(jd, dd) * wd.to(dev)).sum().backward()
+        if M > 1:       # (M == 1: a 1-vector is read as compact 1x1, same thing)
+            assert torch.allclose(dd.grad.cpu(), dc.grad, rtol=1e-10, atol=1e-11), (M, d)
+        assert torch.allclose(jd.grad.cpu(), jc.grad, rtol=1e-10, atol=1e-11), (M, d)
