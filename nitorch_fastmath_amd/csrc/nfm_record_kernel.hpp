@@ -332,27 +332,62 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     if (a == nullptr) a = &none;
     if (b == nullptr) b = &none;
     if (c == nullptr) c = &none;
-    const bool ta = L::A::can_tile && tile_ok(a, RA::C, RA::R, RA::Cc, n_outer, n_inner, sizeof(T));
-    const bool tb = L::B::can_tile && tile_ok(b, RB::C, RB::R, RB::Cc, n_outer, n_inner, sizeof(T));
-    const bool tc = L::C::can_tile && tile_ok(c, RC::C, RC::R, RC::Cc, n_outer, n_inner, sizeof(T));
-    const bool to = L::O::can_tile && tile_ok(out, RO::C, RO::R, RO::Cc, n_outer, n_inner, sizeof(T));
-    auto mode = [&](bool tiled, bool can_vec, bool can_soa, const nfm_operand *op, int C, int R, int Cc) {
-        if (tiled) return (int)MODE_TILED;
-        if (can_vec && vec_ok(op, C, R, Cc, n_outer, sizeof(T))) return (int)MODE_VEC;
-        if (can_soa && soa_ok(op, C, R, sizeof(T))) return (int)MODE_SOA;
-        return (int)MODE_STRIDED;
-    };
-    const int ma = mode(ta, L::A::can_vec, L::A::can_soa, a, RA::C, RA::R, RA::Cc);
-    const int mb = mode(tb, L::B::can_vec, L::B::can_soa, b, RB::C, RB::R, RB::Cc);
-    const int mc = mode(tc, L::C::can_vec, L::C::can_soa, c, RC::C, RC::R, RC::Cc);
-    const int mo = mode(to, L::O::can_vec, L::O::can_soa, out, RO::C, RO::R, RO::Cc);
-    const bool any = ta || tb || tc || to || ma == MODE_SOA || mb == MODE_SOA || mc == MODE_SOA || mo == MODE_SOA;
-    // FAST path: every used operand in its preferred mode (an absent C operand is fine)
     const bool c_absent = c->ptr == nullptr;
-    const bool fast = n_outer == 1 && (!RA::used || ma == L::A::pref) && (!RB::used || mb == L::B::pref) &&
-                      (!RC::used || c_absent || mc == L::C::pref) && mo == L::O::pref &&
-                      L::A::pref != MODE_STRIDED && L::O::pref != MODE_STRIDED &&
-                      (!RB::used || L::B::pref != MODE_STRIDED) && (!RC::used || L::C::pref != MODE_STRIDED);
+    struct Modes {
+        int ma, mb, mc, mo;
+        bool any, fast;
+    };
+    // movement mode of every operand for a batch of n records starting at the given pointers
+    auto classify = [&](const nfm_operand *pa, const nfm_operand *pb, const nfm_operand *pc,
+                        const nfm_operand *po, int64_t n) {
+        const bool ta = L::A::can_tile && tile_ok(pa, RA::C, RA::R, RA::Cc, n_outer, n, sizeof(T));
+        const bool tb = L::B::can_tile && tile_ok(pb, RB::C, RB::R, RB::Cc, n_outer, n, sizeof(T));
+        const bool tc = L::C::can_tile && tile_ok(pc, RC::C, RC::R, RC::Cc, n_outer, n, sizeof(T));
+        const bool to = L::O::can_tile && tile_ok(po, RO::C, RO::R, RO::Cc, n_outer, n, sizeof(T));
+        auto mode = [&](bool tiled, bool can_vec, bool can_soa, const nfm_operand *op, int C, int R, int Cc) {
+            if (tiled) return (int)MODE_TILED;
+            if (can_vec && vec_ok(op, C, R, Cc, n_outer, sizeof(T))) return (int)MODE_VEC;
+            if (can_soa && soa_ok(op, C, R, sizeof(T))) return (int)MODE_SOA;
+            return (int)MODE_STRIDED;
+        };
+        Modes m;
+        m.ma = mode(ta, L::A::can_vec, L::A::can_soa, pa, RA::C, RA::R, RA::Cc);
+        m.mb = mode(tb, L::B::can_vec, L::B::can_soa, pb, RB::C, RB::R, RB::Cc);
+        m.mc = mode(tc, L::C::can_vec, L::C::can_soa, pc, RC::C, RC::R, RC::Cc);
+        m.mo = mode(to, L::O::can_vec, L::O::can_soa, po, RO::C, RO::R, RO::Cc);
+        m.any = ta || tb || tc || to || m.ma == MODE_SOA || m.mb == MODE_SOA || m.mc == MODE_SOA ||
+                m.mo == MODE_SOA;
+        // FAST path: every used operand in its preferred mode (an absent C operand is fine)
+        m.fast = n_outer == 1 && (!RA::used || m.ma == L::A::pref) && (!RB::used || m.mb == L::B::pref) &&
+                 (!RC::used || c_absent || m.mc == L::C::pref) && m.mo == L::O::pref &&
+                 L::A::pref != MODE_STRIDED && L::O::pref != MODE_STRIDED &&
+                 (!RB::used || L::B::pref != MODE_STRIDED) && (!RC::used || L::C::pref != MODE_STRIDED);
+        return m;
+    };
+    Modes md = classify(a, b, c, out, n_inner);
+    if constexpr (!FAST_ONLY) {
+        // Contiguous batch-major operands whose base is not 16-byte aligned (an odd row offset
+        // of a sliced tensor): peel the first r records off into a tiny run-time-mode launch if
+        // the rest of the batch then starts aligned for EVERY operand.
+        if (!md.fast && n_outer == 1) {
+            const int V = 16 / (int)sizeof(T);
+            for (int r = 1; r < V && r < n_inner; ++r) {
+                auto shifted = [&](const nfm_operand *op) {
+                    nfm_operand s = *op;
+                    if (s.ptr) s.ptr = static_cast<char *>(s.ptr) + (int64_t)r * s.stride_inner * (int64_t)sizeof(T);
+                    return s;
+                };
+                const nfm_operand sa = shifted(a), sb = shifted(b), sc = shifted(c), so = shifted(out);
+                if (classify(&sa, &sb, &sc, &so, n_inner - r).fast) {
+                    const int rc = rec_launch<T, Op, false>(a, b, c, out, 1, r, prm, stream);
+                    if (rc != NFM_OK) return rc;
+                    return rec_launch<T, Op, false>(&sa, &sb, &sc, &so, 1, n_inner - r, prm, stream);
+                }
+            }
+        }
+    }
+    const int ma = md.ma, mb = md.mb, mc = md.mc, mo = md.mo;
+    const bool any = md.any, fast = md.fast;
     const int64_t nblk = (n_inner + Op::TILE - 1) / Op::TILE;
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
     dim3 grid((unsigned)nblk, (unsigned)n_outer, 1), block(Op::TILE, 1, 1);

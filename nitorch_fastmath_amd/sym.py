@@ -67,8 +67,24 @@ def _prep(dtype, *tensors):
     return dev, dtype, [None if t is None else t.to(dtype) for t in tensors]
 
 
-def _alloc_out(out, shape, dtype, device):
+def _alloc_out(out, shape, dtype, device, like=None):
     if out is None:
+        # a channel-first (component-major) operand of the output's shape hands its layout on:
+        # the whole call then runs through the SoA tiles and downstream ops keep the field layout
+        if (like is not None and tuple(like.shape) == tuple(shape) and like.dim() >= 2
+                and like.stride(-1) != 1 and not like.is_contiguous()
+                and like.numel() > 0 and 0 not in like.stride()):
+            cand = torch.empty_like(like, dtype=dtype)      # preserve_format keeps dense strides
+            if cand.stride() == like.stride():
+                return cand, None
+        # a contiguous operand that starts inside a 16-byte vector (rows i0.. of a larger tensor)
+        # hands its phase on, so that peeling a few records aligns inputs AND output together
+        if (like is not None and tuple(like.shape) == tuple(shape) and like.is_contiguous()
+                and like.dtype == dtype and like.data_ptr() % 16 != 0 and like.numel() > 0):
+            es = like.element_size()
+            off = (like.data_ptr() % 16) // es
+            n = like.numel()
+            return torch.empty(n + 16 // es, dtype=dtype, device=device)[off:off + n].view(shape), None
         return torch.empty(shape, dtype=dtype, device=device), None
     if tuple(out.shape) != tuple(shape):
         raise ValueError(f'out has shape {tuple(out.shape)}, expected {tuple(shape)}')
@@ -94,7 +110,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
     batch = broadcast_shapes(*shapes)
     if inp is not None and inp.shape[-1] != N:
         raise ValueError('inp and vec must have the same number of components')
-    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev)
+    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec)
     ops = [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1)]
     ncs = [mat_nc, 1]
     if inp is not None:
@@ -202,7 +218,7 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     kind = _mat_kind(mat.shape[-1], N)
     matv, mat_nc = _full_view(mat, N, kind)
     batch = broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
-    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev)
+    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec)
     b = Batch(batch, [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1), out], [mat_nc, 1, 1],
               pack=N > 8 and kind == _lib.MAT_SYM)
     o = b.operands
@@ -248,7 +264,7 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
     M = _nb_prm(mat.shape[-1])
     _check_order(M)
     batch = mat.shape[:-1]
-    out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev)
+    out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=mat)
     b = Batch(batch, [mat, out], [1, 1], pack=M > 8 and not diag)
     o = b.operands
     with torch.cuda.device(dev):

@@ -45,6 +45,7 @@ for M in (4, 6):
     cases.append(('two-level batch (rows of a strided 2-D field)', m3, v3, (K + 2 * M) * 4))
     mis = torch.empty(n * K + 1, device=dev)[1:].view(n, K).copy_(mat)
     cases.append(('base pointer off by 4 bytes', mis, vec, (K + 2 * M) * 4))
+    cases.append(('rows 1.. of the contiguous tensors (x[1:])', mat[1:], vec[1:], (K + 2 * M) * 4))
     for name, m, v, bpu in cases:
         nn = max(m.shape[:-1].numel(), v.shape[:-1].numel())
         t = timeit(lambda: N.sym_solve(m, v))

@@ -66,7 +66,11 @@ def T(x):
 
 count = fails = 0
 t_end = time.time() + budget
+t_last = time.time()
 while time.time() < t_end:
+    if time.time() - t_last > 45:      # keep the run visibly alive
+        print(f'... {count} cases, {fails} failures', flush=True)
+        t_last = time.time()
     dtype = [np.float32, np.float64][rng.integers(0, 2)]
     M = int(rng.integers(1, 17))
     op = ['solve', 'matvec', 'addmatvec', 'invert', 'invert_diag', 'det', 'batchinv', 'batchdet', 'batchmatvec', 'nansum',

@@ -65,7 +65,11 @@ def check(x, xd, what):
 
 t0 = time.time()
 n = 0
+t_last = time.time()
 while time.time() - t0 < budget:
+    if time.time() - t_last > 45:      # keep the run visibly alive
+        print(f'... {n} shapes', flush=True)
+        t_last = time.time()
     o, r, i = pick_shape()
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     mean = float(rng.choice([0.0, 0.0, 1e3, -1e5]))

@@ -267,3 +267,31 @@ def test_large_roundtrip_properties(dev, M, n):
     inv = S.sym_invert(mat)
     e = S.sym_matvec(inv, y)            # inv(A) (A v) == v
     assert ((e - v).abs().amax() / v.abs().amax()).item() < 2e-5
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [2, 3, 4, 5, 6, 8])
+def test_odd_row_offsets_of_contiguous_tensors(dev, oracle, dn, M):
+    """slices `x[i0:]` of contiguous (n, K) tensors start at any multiple of the record size:
+    the launcher peels 1..3 records off so that the rest runs through the aligned tile path
+    (or falls back to per-lane loads when no peel aligns every operand) -- same results"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    S = N().sym
+    ex = M <= 4
+    n = 3000
+    mat, vec = spd_np(n, M, dtype, 300 + M)
+    md, vd = t(mat, dev), t(vec, dev)
+    for i0 in (1, 2, 3, 5):
+        for i1 in (n, n - 1, i0 + 1, i0 + 2, i0 + 300):
+            ref = oracle.sym_solve(mat[i0:i1], vec[i0:i1])
+            check(S.sym_solve(md[i0:i1], vd[i0:i1]), ref, dn, ex)
+            out = torch.full((n, M), 7.0, dtype=vd.dtype, device=dev)
+            S.sym_solve(md[i0:i1], vd[i0:i1], out=out[i0:i1])
+            check(out[i0:i1], ref, dn, ex)
+            assert bool((out[:i0] == 7).all()) and bool((out[i1:] == 7).all())
+            v2 = vd.clone()
+            S.sym_solve_(md[i0:i1], v2[i0:i1])                       # in place on a slice
+            check(v2[i0:i1], ref, dn, ex)
+            assert torch.equal(v2[:i0], vd[:i0]) and torch.equal(v2[i1:], vd[i1:])
+        check(S.sym_invert(md[i0:]), oracle.sym_invert(mat[i0:]), dn, ex)
+        check(S.sym_matvec(md[i0:], vd[i0:]), oracle.sym_matvec(mat[i0:], vec[i0:]), dn, True)
