@@ -110,7 +110,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
     batch = broadcast_shapes(*shapes)
     if inp is not None and inp.shape[-1] != N:
         raise ValueError('inp and vec must have the same number of components')
-    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec)
+    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if N <= 8 else None)
     ops = [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1)]
     ncs = [mat_nc, 1]
     if inp is not None:
@@ -218,7 +218,7 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     kind = _mat_kind(mat.shape[-1], N)
     matv, mat_nc = _full_view(mat, N, kind)
     batch = broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
-    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec)
+    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if N <= 8 else None)
     b = Batch(batch, [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1), out], [mat_nc, 1, 1],
               pack=N > 8 and kind == _lib.MAT_SYM)
     o = b.operands
@@ -264,7 +264,7 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
     M = _nb_prm(mat.shape[-1])
     _check_order(M)
     batch = mat.shape[:-1]
-    out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=mat)
+    out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=mat if M <= 8 else None)
     b = Batch(batch, [mat, out], [1, 1], pack=M > 8 and not diag)
     o = b.operands
     with torch.cuda.device(dev):
