@@ -207,12 +207,13 @@ __global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, O
     const bool sA = !FAST && IA::can_soa && ma == MODE_SOA, sB = !FAST && IB::can_soa && mb == MODE_SOA;
     const bool sC = !FAST && IC::can_soa && mc == MODE_SOA && use_c, sO = !FAST && IO_::can_soa && mo == MODE_SOA;
 
-    typename IA::IO::Stage stA;
-    typename IB::IO::Stage stB;
-    typename IC::IO::Stage stC;
-    typename IA::SO::Stage sqA;
-    typename IB::SO::Stage sqB;
-    typename IC::SO::Stage sqC;
+    // the AoS-tile and SoA-tile staging registers of an operand are never live together
+    union StageA { typename IA::IO::Stage t; typename IA::SO::Stage s; } uA;
+    union StageB { typename IB::IO::Stage t; typename IB::SO::Stage s; } uB;
+    union StageC { typename IC::IO::Stage t; typename IC::SO::Stage s; } uC;
+    auto &stA = uA.t; auto &sqA = uA.s;
+    auto &stB = uB.t; auto &sqB = uB.s;
+    auto &stC = uC.t; auto &sqC = uC.s;
 
     // 1. every 16-byte global load of the tile in flight (no waits in between)
     if constexpr (IA::can_tile)
