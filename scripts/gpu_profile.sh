@@ -8,7 +8,7 @@ TAG=${1:-r01b}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for w in sym_solve4 sym_solve6 batchinv8 nansum; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_$w -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --workload $w > $O/rocprof_${TAG}_$w.log 2>&1; echo "rocprof $w rc=$?"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_$w -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu --workload $w > $O/rocprof_${TAG}_$w.log 2>&1; echo "rocprof $w rc=$?"
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${TAG}_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
@@ -16,7 +16,7 @@ ls $O/pmc_${TAG}_fetch/* | head
 cd $R
 python scripts/parse_pmc.py $O/pmc_${TAG}_fetch $O/pmc_${TAG}_write "SolveOp<float, 4, 0>" $O/traffic_sym_solve4.json sym_solve4
 for w in sym_solve4 sym_solve6 batchinv8 sym_invert3 nansum nanmax; do
-  timeout -k 10 400 python bench.py --steps 20 --warmup 3 --workload $w > $O/bench_${TAG}_$w.log 2>&1; echo "bench $w rc=$?"; tail -1 $O/bench_${TAG}_$w.log | cut -c1-330
+  timeout -k 10 400 python bench.py --steps 100 --warmup 10 --workload $w > $O/bench_${TAG}_$w.log 2>&1; echo "bench $w rc=$?"; tail -1 $O/bench_${TAG}_$w.log | cut -c1-330
 done
 # dim-wise reductions under the profiler (2^28 elements per shape keeps the trace short)
 cd /tmp
