@@ -121,6 +121,15 @@ int nfm_sym_matmul(int dtype, int K, int D, int hess_kind, int64_t n_outer, int6
                    const nfm_operand *jac, const nfm_operand *hess, const nfm_operand *out,
                    void *stream);
 
+/* EXTENSION (no counterpart in the reference): x = (J^T H J)^-1 g in one kernel -- the
+ * Gauss-Newton step its callers chain as `sym_solve(sym_matmul(jac, hess), grad, eps)`
+ * (`_impl/sym.py:637-670` then `:327-398`), without the HBM round trip of the compact
+ * (D x D) product.  Same arithmetic as the two calls: bit-identical results.  K, D in 1..4
+ * (NFM_ESIZE otherwise: chain the two calls); eps as for nfm_sym_solve, length D. */
+int nfm_sym_matmul_solve(int dtype, int K, int D, int hess_kind, int64_t n_outer, int64_t n_inner,
+                         const nfm_operand *jac, const nfm_operand *hess, const nfm_operand *grad,
+                         const nfm_operand *out, const double *eps, void *stream);
+
 /* -------------------------------------------------------------- batched ---- */
 
 #define NFM_FLAG_TS_PERTURB 1 /* add (max|A| - min|A|) * 1e-12 to det for N in {2,3}:

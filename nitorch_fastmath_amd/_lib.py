@@ -39,6 +39,7 @@ SIGNATURES = {
     'nfm_sym_outer': [_i, _i, _i64, _i64, _op, _op, _vp],
     'nfm_sym_outer2': [_i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_sym_matmul': [_i, _i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
+    'nfm_sym_matmul_solve': [_i, _i, _i, _i, _i64, _i64, _op, _op, _op, _op, _dp, _vp],
     'nfm_batch_inv': [_i, _i, _i, _i64, _i64, _op, _op, _vp],
     'nfm_batch_det': [_i, _i, _i64, _i64, _op, _op, _vp],
     'nfm_batch_matvec': [_i, _i, _i, _i64, _i64, _op, _op, _op, _vp],

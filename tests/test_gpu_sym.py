@@ -295,3 +295,47 @@ def test_odd_row_offsets_of_contiguous_tensors(dev, oracle, dn, M):
             assert torch.equal(v2[:i0], vd[:i0]) and torch.equal(v2[i1:], vd[i1:])
         check(S.sym_invert(md[i0:]), oracle.sym_invert(mat[i0:]), dn, ex)
         check(S.sym_matvec(md[i0:], vd[i0:]), oracle.sym_matvec(mat[i0:], vec[i0:]), dn, True)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_fused_matmul_solve_equals_the_chain(dev, oracle, dn):
+    """EXTENSION `sym_matmul_solve`: one kernel, bit-identical to sym_solve(sym_matmul(j, h), g, eps)
+    (and therefore to the oracle chain wherever the chain is)"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    S = N().sym
+    rng = np.random.default_rng(17)
+
+    def same(x, y):       # k < d makes J^T H J singular: inf / nan must match too
+        return bool(((x == y) | (torch.isnan(x) & torch.isnan(y))).all())
+    n = 1237
+    for k in (1, 2, 3, 4):
+        for d in (1, 2, 3, 4):
+            j = rng.standard_normal((n, k, d)).astype(dtype) + (np.eye(k, d, dtype=dtype) * 2)
+            h, _ = spd_np(n, k, dtype, 500 + 10 * k + d)
+            g = rng.standard_normal((n, d)).astype(dtype)
+            jd, hd, gd = t(j, dev), t(h, dev), t(g, dev)
+            for eps in (None, 0.25, [0.5, 0.125]):
+                chain = S.sym_solve(S.sym_matmul(jd, hd), gd, eps=eps)
+                fused = S.sym_matmul_solve(jd, hd, gd, eps=eps)
+                assert same(fused, chain), (k, d, eps)
+            a = oracle.sym_matmul(j, h)
+            ref = oracle.sym_solve(a, g)
+            assert np.array_equal(S.sym_matmul_solve(jd, hd, gd).cpu().numpy(), ref, equal_nan=True), (k, d)
+            # diagonal hessian, channel-first operands, one hessian for all jacobians
+            hdiag = hd[:, :k].contiguous()
+            assert same(S.sym_matmul_solve(jd, hdiag, gd), S.sym_solve(S.sym_matmul(jd, hdiag), gd))
+            jc = jd.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+            hc, gc = hd.t().contiguous().t(), gd.t().contiguous().t()
+            r = S.sym_matmul_solve(jc, hc, gc)
+            assert same(r, S.sym_solve(S.sym_matmul(jd, hd), gd))
+            if d > 1:
+                assert r.stride(-1) != 1          # channel-first in, channel-first out
+            assert same(S.sym_matmul_solve(jd, hd[:1], gd), S.sym_solve(S.sym_matmul(jd, hd[:1]), gd))
+    # sizes beyond 4 run the chain; gradients flow through the chain's autograd
+    j = torch.randn(50, 5, 3, device=dev, dtype=torch.float64)
+    h, _ = spd_np(50, 5, np.float64, 1)
+    g = torch.randn(50, 3, device=dev, dtype=torch.float64)
+    assert torch.equal(S.sym_matmul_solve(j, t(h, dev), g), S.sym_solve(S.sym_matmul(j, t(h, dev)), g))
+    jr = torch.randn(9, 3, 3, device=dev, dtype=torch.float64, requires_grad=True)
+    S.sym_matmul_solve(jr, t(spd_np(9, 3, np.float64, 2)[0], dev), torch.randn(9, 3, device=dev, dtype=torch.float64)).sum().backward()
+    assert jr.grad is not None and bool(torch.isfinite(jr.grad).all())
