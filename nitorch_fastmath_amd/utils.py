@@ -2,8 +2,10 @@
 sub indices, machine epsilon."""
 from types import GeneratorType as generator
 import torch
+from builtins import max as builtins_max
 
-__all__ = ['ensure_list', 'ind2sub', 'sub2ind', 'eps']
+__all__ = ['ensure_list', 'ind2sub', 'sub2ind', 'eps', 'fast_slice_tensor', 'slice_tensor', 'cumprod',
+           'broadcast_backward', 'graphed']
 
 
 def ensure_list(x, size=None, crop=True, **kwargs):
@@ -57,6 +59,64 @@ def eps(dtype='float32'):
     if dtype in ('float64', torch.float64, 'complex128', torch.complex128):
         return 2 ** -52
     raise NotImplementedError
+
+
+def fast_slice_tensor(x, index, dim=-1):
+    """`x[..., index, ...]` along one dim with native indexing: a view when `index` is a slice or int
+    (`utils.py:30-57`)."""
+    key = [slice(None)] * x.dim()
+    key[dim] = index
+    return x[tuple(key)]
+
+
+def slice_tensor(x, index, dim=None):
+    """Native indexing along one or several dims (`utils.py:60-108`): `index` is one index or a
+    tuple of indices (ints, lists, slices, long tensors; no ellipsis, no masks), `dim` the dims they
+    apply to (default: the last `len(index)` dims)."""
+    if not isinstance(index, tuple):
+        index = (index,)
+    dims = list(range(-len(index), 0)) if dim is None else ensure_list(dim)
+    n = builtins_max(len(index), len(dims))
+    dims, index = ensure_list(dims, n), ensure_list(list(index), n)
+    key = [slice(None)] * x.dim()
+    for d, ind in zip(dims, index):
+        if ind is Ellipsis or (torch.is_tensor(ind) and ind.dtype == torch.bool):
+            raise TypeError('`index` cannot be an ellipsis or mask')
+        key[d] = ind
+    return x[tuple(key)]
+
+
+def cumprod(sequence, reverse=False, exclusive=False):
+    """Cumulative product of a sequence as a list (`utils.py:111-145`):
+    `reverse`: right to left, `[a*b*c, b*c, c]`; `exclusive`: shifted, `[1, a, a*b]`."""
+    items = list(sequence)
+    if reverse:
+        items.reverse()
+    out, acc = [], None
+    for e in items:
+        acc = e if acc is None else acc * e
+        out.append(acc)
+    if exclusive:
+        out = [1] + out[:-1]
+    if reverse:
+        out.reverse()
+    return out
+
+
+def broadcast_backward(input, shape):
+    """Sum a broadcast tensor back to the original `shape` (`utils.py:252-279`)."""
+    shape = tuple(shape)
+    lead = input.dim() - len(shape)
+    if lead < 0:
+        raise ValueError(f'Shapes not compatible for broadcast: {tuple(input.shape)} and {shape}')
+    for k, s in enumerate(shape):
+        if s != input.shape[lead + k]:
+            if s != 1:
+                raise ValueError(f'Shapes not compatible for broadcast: {tuple(input.shape)} and {shape}')
+            input = input.sum(dim=lead + k, keepdim=True)
+    if lead:
+        input = input.sum(dim=list(range(lead)))
+    return input
 
 
 class graphed:

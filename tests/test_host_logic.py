@@ -87,3 +87,24 @@ def test_output_allocation_policy_needs_no_gpu_to_decide():
     assert out.is_contiguous() and out.data_ptr() % 16 == sl.data_ptr() % 16     # same phase
     with pytest.raises(ValueError):
         _alloc_out(torch.zeros(3, 4), (1000, 4), torch.float32, cpu)
+
+
+def test_utils_helpers_follow_the_reference_docstrings():
+    """`utils.py:30-145,252-279` (semantics pinned against the reference in the build container)"""
+    from nitorch_fastmath_amd import utils as U
+    x = torch.arange(2 * 3 * 4 * 5.).reshape(2, 3, 4, 5)
+    assert torch.equal(U.fast_slice_tensor(x, slice(1, 3), 2), x[:, :, 1:3])
+    assert U.fast_slice_tensor(x, slice(1, 3), 2).data_ptr() == x[:, :, 1:3].data_ptr()      # a view
+    assert torch.equal(U.slice_tensor(x, (1, slice(0, 2)), [1, 3]), x[:, 1, :, 0:2])
+    assert torch.equal(U.slice_tensor(x, [0, 2]), x[..., [0, 2]])
+    with pytest.raises(TypeError):
+        U.slice_tensor(x, Ellipsis)
+    assert U.cumprod([2, 3, 4]) == [2, 6, 24]
+    assert U.cumprod([2, 3, 4], reverse=True) == [24, 12, 4]
+    assert U.cumprod([2, 3, 4], exclusive=True) == [1, 2, 6]
+    assert U.cumprod([2, 3, 4], reverse=True, exclusive=True) == [12, 4, 1]
+    g = torch.randn(4, 2, 3, 5)
+    assert torch.allclose(U.broadcast_backward(g, (1, 3, 5)), g.sum(0).sum(0, keepdim=True))
+    assert U.broadcast_backward(g, (4, 2, 3, 5)) is g
+    with pytest.raises(ValueError):
+        U.broadcast_backward(g, (2, 2, 5))
