@@ -307,9 +307,10 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                     break;
                 }
                 if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
+                    // |prev - new| / prev < tol * 1e-3, written without the fp64 division (prev > 0)
                     const double sos_new = (double)(sos_lower / sos_diag);
-                    const double rel = (sos_prev - sos_new) / sos_prev;
-                    if (sos_prev != 0.0 && (rel < 0 ? -rel : rel) < tol * 1e-3) break;
+                    const double dif = sos_prev - sos_new;
+                    if (sos_prev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sos_prev) break;
                     sos_prev = sos_new;
                 }
             }
