@@ -101,9 +101,9 @@ __device__ __forceinline__ void rec_vec_store(const Opnd &op, int64_t o, int64_t
     }
 }
 
-template <typename T, class Op>
+template <typename T, class Op, int TILE_ = Op::TILE>
 struct RecLayout {
-    static constexpr int TILE = Op::TILE;
+    static constexpr int TILE = TILE_;
     using A = RecIO<T, typename Op::RA, TILE>;
     using B = RecIO<T, typename Op::RB, TILE>;
     using C = RecIO<T, typename Op::RC, TILE>;
@@ -166,22 +166,40 @@ struct op_streams<Op, std::void_t<decltype(Op::kStream)>> : std::bool_constant<O
 // operand through the SoA image.  KIND_ANY keeps the wave-uniform run-time modes for mixed,
 // broadcast and strided operands.
 enum { KIND_ANY = 0, KIND_AOS = 1, KIND_SOA = 2 };
+
+// lanes per workgroup of a kernel variant: Op::TILE, unless the Op names another size for its
+// AoS variant (`kAosTile`: the 4x4 fp32 solve runs 512-lane tiles there, measured +2-3 % in
+// same-box A/B runs; the other small-record Ops measured flat or slightly worse at 512).
+template <class Op, class = void>
+struct op_aos_tile {
+    static constexpr int value = Op::TILE;
+};
+template <class Op>
+struct op_aos_tile<Op, std::void_t<decltype(Op::kAosTile)>> {
+    static constexpr int value = Op::kAosTile;
+};
 template <typename T, class Op, int KIND>
-__global__ __launch_bounds__(Op::TILE) void rec_kernel(Opnd a, Opnd b, Opnd c, Opnd out, int64_t n_inner,
-                                                       typename Op::Params prm)
+struct KindTile {
+    static constexpr int value = KIND == KIND_AOS ? op_aos_tile<Op>::value : Op::TILE;
+};
+
+template <typename T, class Op, int KIND>
+__global__ __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opnd a, Opnd b, Opnd c, Opnd out,
+                                                                          int64_t n_inner,
+                                                                          typename Op::Params prm)
 {
     constexpr bool FAST = KIND == KIND_AOS;
     constexpr bool SFAST = KIND == KIND_SOA;
-    using L = RecLayout<T, Op>;
+    constexpr int TILE = KindTile<T, Op, KIND>::value;
+    using L = RecLayout<T, Op, TILE>;
     using RA = typename Op::RA;
     using RB = typename Op::RB;
     using RC = typename Op::RC;
     using RO = typename Op::RO;
-    using IA = RecIO<T, RA, Op::TILE>;
-    using IB = RecIO<T, RB, Op::TILE>;
-    using IC = RecIO<T, RC, Op::TILE>;
-    using IO_ = RecIO<T, RO, Op::TILE>;
-    constexpr int TILE = Op::TILE;
+    using IA = RecIO<T, RA, TILE>;
+    using IB = RecIO<T, RB, TILE>;
+    using IC = RecIO<T, RC, TILE>;
+    using IO_ = RecIO<T, RO, TILE>;
     extern __shared__ __align__(16) unsigned char smem[];
 
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
@@ -389,14 +407,17 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     }
     const int ma = md.ma, mb = md.mb, mc = md.mc, mo = md.mo;
     const bool any = md.any, fast = md.fast;
-    const int64_t nblk = (n_inner + Op::TILE - 1) / Op::TILE;
+    constexpr int TILE_F = KindTile<T, Op, KIND_AOS>::value; // lanes per workgroup of the AoS variant
+    using LF = RecLayout<T, Op, TILE_F>;
+    const int tile = fast ? TILE_F : Op::TILE;
+    const int64_t nblk = (n_inner + tile - 1) / tile;
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
-    dim3 grid((unsigned)nblk, (unsigned)n_outer, 1), block(Op::TILE, 1, 1);
+    dim3 grid((unsigned)nblk, (unsigned)n_outer, 1), block(tile, 1, 1);
     const size_t lds = any ? (size_t)L::gtotal : 0;
     static bool attr_done = false; // > 64 KiB dynamic LDS needs an opt-in, once per kernel
     if (L::gtotal > 64 * 1024 && !attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_AOS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LF::total);
         if constexpr (!FAST_ONLY) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_ANY>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
@@ -406,7 +427,7 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
         attr_done = true;
     }
     if (fast) {
-        hipLaunchKernelGGL((rec_kernel<T, Op, KIND_AOS>), grid, block, (size_t)L::total,
+        hipLaunchKernelGGL((rec_kernel<T, Op, KIND_AOS>), grid, block, (size_t)LF::total,
                            static_cast<hipStream_t>(stream), make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc),
                            make_opnd(out, mo), n_inner, prm);
     } else {

@@ -29,6 +29,8 @@ struct SolveOp {
     using RO = Rec<1, M>;
     using Params = SolveParams;
     static constexpr int TILE = pick_tile((RA::C + RB::C) * (int)sizeof(T) + 16);
+    // contiguous 4x4 fp32 systems (the headline configuration): 512-lane tiles, see KindTile
+    static constexpr int kAosTile = (M == 4 && KIND == NFM_MAT_SYM && sizeof(T) == 4) ? 512 : TILE;
     static __device__ __forceinline__ void apply(T (&a)[RA::Cs], const T (&v)[M], const T (&)[1], T (&x)[M],
                                                  const Params &p)
     {
