@@ -29,8 +29,9 @@ struct SolveOp {
     using RO = Rec<1, M>;
     using Params = SolveParams;
     static constexpr int TILE = pick_tile((RA::C + RB::C) * (int)sizeof(T) + 16);
-    // contiguous 4x4 fp32 systems (the headline configuration): 512-lane tiles, see KindTile
-    static constexpr int kAosTile = (M == 4 && KIND == NFM_MAT_SYM && sizeof(T) == 4) ? 512 : TILE;
+    // contiguous 4x4 / 6x6 fp32 systems (configurations C2 / C5): 512-lane tiles, +2-4 % in same-box
+    // A/B runs at 1e8 systems (see KindTile); the other orders measured flat within run-to-run noise
+    static constexpr int kAosTile = ((M == 4 || M == 6) && KIND == NFM_MAT_SYM && sizeof(T) == 4) ? 512 : TILE;
     static __device__ __forceinline__ void apply(T (&a)[RA::Cs], const T (&v)[M], const T (&)[1], T (&x)[M],
                                                  const Params &p)
     {
