@@ -18,6 +18,8 @@ struct BatchInvOp {
     using RO = Rec<N, N>;
     using Params = InvParams;
     static constexpr int TILE = pick_tile(RA::C * (int)sizeof(T) + 16);
+    // 8x8 fp64 (configuration C3): two wavefronts per workgroup, +2 % in same-box A/B runs (256: -20 %)
+    static constexpr int kAosTile = (N == 8 && sizeof(T) == 8) ? 128 : TILE;
     static __device__ __forceinline__ void apply(const T (&a)[RA::Cs], const T (&)[1], const T (&)[1],
                                                  T (&r)[RO::Cs], const Params &p)
     {
