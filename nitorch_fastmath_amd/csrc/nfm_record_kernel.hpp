@@ -165,7 +165,7 @@ struct op_streams<Op, std::void_t<decltype(Op::kStream)>> : std::bool_constant<O
 // KIND_SOA = the same for component-major (channel-first) fields: every multi-component
 // operand through the SoA image.  KIND_ANY keeps the wave-uniform run-time modes for mixed,
 // broadcast and strided operands.
-enum { KIND_ANY = 0, KIND_AOS = 1, KIND_SOA = 2 };
+enum { KIND_ANY = 0, KIND_AOS = 1, KIND_SOA = 2, KIND_SOAW = 3 }; // SOAW: SoA with 512-lane tiles
 
 // lanes per workgroup of a kernel variant: Op::TILE, unless the Op names another size for its
 // AoS variant (`kAosTile`: the 4x4 fp32 solve runs 512-lane tiles there, measured +2-3 % in
@@ -182,6 +182,13 @@ template <typename T, class Op, int KIND>
 struct KindTile {
     static constexpr int value = KIND == KIND_AOS ? op_aos_tile<Op>::value : Op::TILE;
 };
+// Component runs that do not start on 16-byte boundaries (odd voxel counts) pay per tile for the
+// two straddling vectors of every component: 512-lane tiles halve that (4x4 solve: +7 %), while
+// aligned runs are better off at 256 (-4 % at 512).  Only Ops whose SoA image fits 64 KiB.
+template <typename T, class Op>
+struct KindTile<T, Op, KIND_SOAW> {
+    static constexpr int value = (Op::TILE == 256 && RecLayout<T, Op, 512>::gtotal <= 64 * 1024) ? 512 : Op::TILE;
+};
 
 template <typename T, class Op, int KIND>
 __global__ __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opnd a, Opnd b, Opnd c, Opnd out,
@@ -189,7 +196,7 @@ __global__ __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opn
                                                                           typename Op::Params prm)
 {
     constexpr bool FAST = KIND == KIND_AOS;
-    constexpr bool SFAST = KIND == KIND_SOA;
+    constexpr bool SFAST = KIND == KIND_SOA || KIND == KIND_SOAW;
     constexpr int TILE = KindTile<T, Op, KIND>::value;
     using L = RecLayout<T, Op, TILE>;
     using RA = typename Op::RA;
@@ -439,7 +446,35 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
                                L::A::pref_soa != MODE_STRIDED && L::O::pref_soa != MODE_STRIDED &&
                                (!RB::used || L::B::pref_soa != MODE_STRIDED) &&
                                (!RC::used || L::C::pref_soa != MODE_STRIDED);
-            if (sfast)
+            constexpr int TILE_W = KindTile<T, Op, KIND_SOAW>::value;
+            bool wide = false;
+            if constexpr (TILE_W != Op::TILE) {
+                // does any component run of any SoA operand start off a 16-byte boundary?
+                auto off16 = [&](const nfm_operand *op, int mode, int rows) {
+                    if (mode != MODE_SOA || op->ptr == nullptr) return false;
+                    const int64_t v = 16 / (int64_t)sizeof(T);
+                    return reinterpret_cast<uintptr_t>(op->ptr) % 16 != 0 || op->stride_col % v != 0 ||
+                           op->stride_outer % v != 0 || (rows > 1 && op->stride_row % v != 0);
+                };
+                wide = sfast && (off16(a, ma, RA::R) || off16(b, mb, RB::R) || (!c_absent && off16(c, mc, RC::R)) ||
+                                 off16(out, mo, RO::R));
+            }
+            if (sfast && wide) {
+                if constexpr (TILE_W != Op::TILE) {
+                    using LW = RecLayout<T, Op, TILE_W>;
+                    static bool attr_w = false;
+                    if (LW::gtotal > 64 * 1024 && !attr_w) {
+                        hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_SOAW>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LW::gtotal);
+                        attr_w = true;
+                    }
+                    const int64_t nb = (n_inner + TILE_W - 1) / TILE_W;
+                    hipLaunchKernelGGL((rec_kernel<T, Op, KIND_SOAW>), dim3((unsigned)nb, (unsigned)n_outer, 1),
+                                       dim3(TILE_W, 1, 1), (size_t)LW::gtotal, static_cast<hipStream_t>(stream),
+                                       make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc), make_opnd(out, mo),
+                                       n_inner, prm);
+                }
+            } else if (sfast)
                 hipLaunchKernelGGL((rec_kernel<T, Op, KIND_SOA>), grid, block, lds,
                                    static_cast<hipStream_t>(stream), make_opnd(a, ma), make_opnd(b, mb),
                                    make_opnd(c, mc), make_opnd(out, mo), n_inner, prm);
