@@ -422,7 +422,7 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     dim3 grid((unsigned)nblk, (unsigned)n_outer, 1), block(tile, 1, 1);
     const size_t lds = any ? (size_t)L::gtotal : 0;
     static bool attr_done = false; // > 64 KiB dynamic LDS needs an opt-in, once per kernel
-    if (L::gtotal > 64 * 1024 && !attr_done) {
+    if ((L::gtotal > 64 * 1024 || LF::total > 64 * 1024) && !attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_AOS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LF::total);
         if constexpr (!FAST_ONLY) {
