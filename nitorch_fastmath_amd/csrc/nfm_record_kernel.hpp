@@ -184,10 +184,13 @@ struct KindTile {
 };
 // Component runs that do not start on 16-byte boundaries (odd voxel counts) pay per tile for the
 // two straddling vectors of every component: 512-lane tiles halve that (4x4 solve: +7 %), while
-// aligned runs are better off at 256 (-4 % at 512).  Only Ops whose SoA image fits 64 KiB.
+// aligned runs are better off at 256 (-4 % at 512).  Only Ops whose SoA image fits 80 KiB (6x6: +8 %).
 template <typename T, class Op>
 struct KindTile<T, Op, KIND_SOAW> {
-    static constexpr int value = (Op::TILE == 256 && RecLayout<T, Op, 512>::gtotal <= 64 * 1024) ? 512 : Op::TILE;
+#ifndef NFM_SOAW_LIMIT
+#define NFM_SOAW_LIMIT (80 * 1024) // two 512-lane workgroups per CU
+#endif
+    static constexpr int value = (Op::TILE == 256 && RecLayout<T, Op, 512>::gtotal <= NFM_SOAW_LIMIT) ? 512 : Op::TILE;
 };
 
 template <typename T, class Op, int KIND>
