@@ -84,9 +84,15 @@ def test_pivoting_and_layouts(dev, oracle, n):
 
 @pytest.mark.parametrize('n', [2, 3, 4, 8])
 def test_matrix_first_storage_tiles(dev, oracle, n):
-    """(n, n, B, S) storage viewed as (B, S, n, n): aligned component runs -> SoA tile path"""
-    rng = np.random.default_rng(40 + n)
-    Bn, Sn = 3, 340
+    """(n, n, B, S) storage viewed as (B, S, n, n): component runs -> SoA tile path; S = 340 keeps
+    the runs 16-byte aligned (256-lane tiles), S = 341 / 1031 does not (shifted images, and the
+    512-lane variant where the image fits)"""
+    for Bn, Sn in ((3, 340), (3, 341), (2, 1031), (1, 7)):
+        _matrix_first_case(dev, oracle, n, Bn, Sn)
+
+
+def _matrix_first_case(dev, oracle, n, Bn, Sn):
+    rng = np.random.default_rng(40 + n + Sn)
     a = rng.standard_normal((Bn, Sn, n, n)) + 6 * np.eye(n)
     ad = t(a, dev).permute(2, 3, 0, 1).contiguous().permute(2, 3, 0, 1)
     assert not ad.is_contiguous()
