@@ -25,6 +25,17 @@ def _prep(*tensors):
     return dev, dtype, [t.to(dtype) for t in tensors]
 
 
+def _like_or_contiguous(like, shape, dtype, dev):
+    """Matrix-first / channel-first operands of the output's shape hand their layout on (the call
+    then runs through the SoA tiles end to end); everything else gets a contiguous output."""
+    if (like is not None and tuple(like.shape) == tuple(shape) and not like.is_contiguous()
+            and like.stride(-1) != 1 and like.numel() > 0 and 0 not in like.stride()):
+        cand = torch.empty_like(like, dtype=dtype)
+        if cand.stride() == like.stride():
+            return cand
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
 def batchdet(a):
     """Batched determinant for large batches of small matrices.
 
@@ -64,7 +75,7 @@ def batchinv(a, perturb=False):
     n = a.shape[-1]
     assert a.shape[-2] == n, 'Expected square matrices'
     batch = a.shape[:-2]
-    out = torch.empty(tuple(batch) + (n, n), dtype=dtype, device=dev)
+    out = _like_or_contiguous(a if n <= 8 else None, tuple(batch) + (n, n), dtype, dev)
     b = Batch(batch, [a, out], [2, 2], pack=n > 8)
     o = b.operands
     flags = _lib.FLAG_TS_PERTURB if perturb else 0
@@ -88,7 +99,7 @@ def batchmatvec(mat, vec):
     if vec.shape[-1] != n:
         raise ValueError(f'matrix {tuple(mat.shape[-2:])} and vector ({vec.shape[-1]},) do not match')
     batch = broadcast_shapes(mat.shape[:-2], vec.shape[:-1])
-    out = torch.empty(tuple(batch) + (m,), dtype=dtype, device=dev)
+    out = _like_or_contiguous(vec if m == n else None, tuple(batch) + (m,), dtype, dev)
     b = Batch(batch, [expand_batch(batch, mat, 2), expand_batch(batch, vec, 1), out], [2, 1, 1])
     o = b.operands
     with torch.cuda.device(dev):
