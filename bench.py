@@ -6,22 +6,37 @@
 Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
 `sym_solve` on 1e8 random 4x4 SPD compact-sym fp32 systems per GPU (AoS layout, the
 default torch layout), inputs resident in HBM before the timed region.  One "step" =
-one pass of the hot path over the whole batch = ONE kernel launch.  For N > 1 the
-driver launches one process per GPU (torch.distributed, backend nccl = RCCL); the batch
-shards embarrassingly, so every rank owns 1e8 systems (weak scaling) and there is no
-collective on the data path -- only the barrier and the max-over-ranks of the wall time.
+one pass of the hot path over the whole batch = ONE kernel launch.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  Either an
+external launcher starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or --
+when `--gpus N` > 1 is given and WORLD_SIZE is NOT set -- this file starts the N ranks
+itself, as child processes, BEFORE anything in the parent touches the GPU (the parent never
+imports torch).  `--gpus` must equal WORLD_SIZE; a mismatch is an error, never a silent
+1-GPU run.  The batch shards embarrassingly, so every rank owns the full per-GPU batch
+(weak scaling) and there is no collective on the data path -- only the barrier, the
+max-over-ranks of the wall time and a census of the ranks/devices (`ranks_seen`, `devices`).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel: algorithmic bytes per launch /
-                  average launch duration (HIP events on the launch stream),
-  "cpu_baseline": the CPU oracle (a C port of the reference's algorithm, OpenMP) timed on
-                  this box's host cores on a bounded sample (rank 0, N = 1 only).
+                  launch duration (HIP events on the launch stream, one per step: mean,
+                  median and min are reported; `achieved` uses the mean);
+  "parity":       a REAL comparison of the last timed step's output against the CPU oracle
+                  (which units, which tolerance, what error) -- a failed check exits non-zero;
+  "cpu_baseline": the reference's CPU path shape timed on this box's host cores on a bounded
+                  sample (rank 0, N = 1 only): the C/OpenMP port of the algorithm and, for the
+                  4x4 solve, the torch-eager restatement of the reference's op sequence at
+                  1 thread and at all threads.
 Other workloads (parity-test configs, for profiling): --workload sym_solve6 | batchinv8 |
-nansum | nanmax | sym_invert3 | eig3.
+nansum | nanmax | sym_invert3 | eig3.  `--workload null` is the launcher self-test (no
+computation; runs on CPU with --backend gloo).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,22 +44,75 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy)
+TOL = {'f32': 1e-6, 'f64': 1e-12}     # BASELINE.json north_star
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=100)
     p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--workload', default='sym_solve4')
     p.add_argument('--n', type=float, default=None, help='batch per GPU (default: the config size)')
-    p.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    p.add_argument('--no-cpu', action='store_true', help='skip the parity + cpu_baseline leg')
     p.add_argument('--layout', default='aos', choices=['aos', 'soa'])
+    p.add_argument('--settle-ms', type=float, default=300.0,
+                   help='after the W warm-up steps keep launching (untimed) for this many ms so that the '
+                        'power-state ramp of the first ~10 launches after an idle gap is over before the timed '
+                        'region starts; the count is reported as settle_steps (0 disables)')
     p.add_argument('--gather', action='store_true',
                    help='also time the OPTIONAL epilogue: all-gather of the per-rank outputs over xGMI (reported '
                         'separately as gather_ms; never part of value)')
-    return p.parse_args()
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help='gloo = CPU launcher self-test, only with --workload null')
+    return p.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------------------------
+# self-launch: N ranks as child processes, started before the parent touches the GPU
+# ----------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a, argv):
+    """Start a.gpus children of this script (rank r on GPU r), wait, propagate failure.
+    Rank 0 inherits stdout, so its JSON line is this process's output."""
+    assert 'torch' not in sys.modules, 'the launcher must not have imported torch'
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   NFM_BENCH_SELF_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f'bench.py: rank {r} exited with {code}; stopping the other ranks', file=sys.stderr)
+                for q in pending.values():      # exactly the PIDs started above
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------
 
 def spd_compact(n, M, dtype, device, seed, chunk=1 << 22):
     """A = G G^T / M + I packed diagonal-first, generated on device in chunks
@@ -67,15 +135,46 @@ def spd_compact(n, M, dtype, device, seed, chunk=1 << 22):
     return mat, vec
 
 
+def head_tail(n, head=1_000_000, tail=100_000):
+    """unit indices checked against the oracle: the first 1e6 of the timed batch
+    and the last 1e5 (the ragged last tiles)"""
+    import torch
+    if n <= head + tail:
+        return torch.arange(n)
+    return torch.cat([torch.arange(head), torch.arange(n - tail, n)])
+
+
+def verdict(got, ref, dn, what, exact_expected=False, scale=None):
+    """parity record: max-norm relative error against the oracle and whether it is within `tol`"""
+    import numpy as np
+    got, ref = np.asarray(got), np.asarray(ref)
+    den = float(scale) if scale is not None else float(np.abs(ref.astype(np.float64)).max())
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / (den if den > 0 else 1.0))
+    exact = bool(np.array_equal(got, ref))
+    ok = exact if exact_expected else bool(err <= TOL[dn])
+    return {'max_rel_err_vs_oracle': err, 'bit_exact_vs_oracle': exact, 'tol': 0.0 if exact_expected else TOL[dn],
+            'checked': what, 'ok': ok}
+
+
 class Workload:
-    """name, unit count per step, algorithmic bytes per unit, the step closure, the cpu leg."""
+    """name, unit count per step, algorithmic bytes per unit, the step closure, the parity check, the cpu leg."""
+    output = None
+    cpu_eager = None
 
 
 def make_workload(name, n_arg, device, rank, layout):
     import torch
-    import nitorch_fastmath_amd as N
     w = Workload()
     seed = 1234 + rank
+    if name == 'null':
+        # launcher / rendezvous / census self-test: no computation, runs anywhere
+        w.units, w.bytes_per_unit, w.dtype = 1, 0, 'none'
+        w.desc, w.metric, w.unit = 'null (launcher self-test, no computation)', 'null steps/sec', 'steps/s'
+        w.step = lambda: None
+        w.kernel = None
+        w.check = w.cpu = None
+        return w
+    import nitorch_fastmath_amd as N
     if name in ('sym_solve4', 'sym_solve6'):
         M = 4 if name == 'sym_solve4' else 6
         n = int(n_arg or 1e8)
@@ -92,24 +191,37 @@ def make_workload(name, n_arg, device, rank, layout):
         w.metric, w.unit = f'{M}x{M} compact-sym solves/sec', 'solves/s'
         w.step = lambda: N.sym_solve(mat, vec, out=out)
         w.output = out
-        w.kernel = f'rec_kernel<float, SolveOp<float, {M}, 0>>'
+        kind = {'aos': 1, 'soa': 2}[layout]
+        w.kernel = f'rec_kernel<float, SolveOp<float, {M}, 0>, {kind}>'
 
         def check():
-            import numpy as np
             import oracle as O
-            idx = torch.cat([torch.arange(0, 50000), torch.arange(n - 50000, n)]).to(device)
+            idx = head_tail(n).to(device)
             ref = O.sym_solve(mat[idx].cpu().numpy(), vec[idx].cpu().numpy())
-            got = out[idx].cpu().numpy()
-            return float(np.abs(got - ref).max() / np.abs(ref).max()), bool(np.array_equal(got, ref))
+            # M <= 4: reference closed forms in the reference's operation order -> bit-identical
+            return verdict(out[idx].cpu().numpy(), ref, 'f32', f'first 1e6 + last 1e5 of {n:.0e} systems',
+                           exact_expected=(M <= 4))
         w.check = check
 
         def cpu(budget_s):
-            import numpy as np
             import oracle as O
             ns = min(n, 20_000_000)
             m_h, v_h = mat[:ns].contiguous().cpu().numpy(), vec[:ns].contiguous().cpu().numpy()
             return time_cpu(lambda: O.sym_solve(m_h, v_h), ns, budget_s), f'first {ns:.0e} systems of the GPU batch'
         w.cpu = cpu
+        if M == 4:
+            def cpu_eager(threads, ns):
+                from oracle import torch_eager as T
+                ns = min(n, ns)
+                m_h, v_h = mat[:ns].contiguous().cpu(), vec[:ns].contiguous().cpu()
+                old = torch.get_num_threads()
+                torch.set_num_threads(threads)
+                try:
+                    rate = time_cpu(lambda: T.sym_solve(m_h, v_h), ns, 0.0, reps_min=1)
+                finally:
+                    torch.set_num_threads(old)
+                return rate, ns
+            w.cpu_eager = cpu_eager
     elif name == 'sym_invert3':
         n = int(n_arg or 1e5)
         mat, _ = spd_compact(n, 3, torch.float64, device, seed)
@@ -118,8 +230,15 @@ def make_workload(name, n_arg, device, rank, layout):
         w.desc = f'sym_invert 3x3 SPD compact-sym fp64, batch {n:.0e}'
         w.metric, w.unit = '3x3 compact-sym inversions/sec', 'inversions/s'
         w.step = lambda: N.sym_invert(mat, out=out)
-        w.kernel = 'rec_kernel<double, InvertOp<double, 3, false>>'
-        w.check = lambda: (0.0, True)
+        w.output = out
+        w.kernel = 'rec_kernel<double, InvertOp<double, 3, false>, 1>'
+
+        def check():
+            import oracle as O
+            idx = head_tail(n).to(device)
+            return verdict(out[idx].cpu().numpy(), O.sym_invert(mat[idx].cpu().numpy()), 'f64',
+                           f'{len(idx):.0e} of {n:.0e} matrices', exact_expected=True)
+        w.check = check
 
         def cpu(budget_s):
             import oracle as O
@@ -134,9 +253,26 @@ def make_workload(name, n_arg, device, rank, layout):
         w.units, w.bytes_per_unit, w.dtype = n, (9 + 3) * 4, 'f32'
         w.desc = f'eig_sym 3x3 symmetric fp32 (eigenvalues), batch {n:.0e}'
         w.metric, w.unit = '3x3 symmetric eigenvalue problems/sec', 'matrices/s'
-        w.step = lambda: N.eig_sym(a, check_finite=False)
-        w.kernel = 'rec_kernel<float, EigSymOp<float, 3, false>>'
-        w.check = lambda: (0.0, True)
+        last = {}
+
+        def step():
+            last['out'] = N.eig_sym(a, check_finite=False)
+        w.step = step
+        w.kernel = 'rec_kernel<float, EigSymOp<float, 3, false>, 1>'
+
+        def check():
+            import numpy as np
+            import oracle as O
+            idx = head_tail(n).to(device)
+            got, ref = last['out'][idx].cpu().numpy(), O.eig_sym(a[idx].cpu().numpy())
+            # eigenvalues are unsorted by contract (qr.py:45-46); the SET must agree within the tolerance;
+            # the deflation order is reported beside it (one extra sweep near the threshold may swap two)
+            v = verdict(np.sort(got, -1), np.sort(ref, -1), 'f32', f'first 1e6 + last 1e5 of {n:.0e} matrices (sorted)')
+            v['tol'] = 4 * TOL['f32']        # same bound as tests/test_gpu_qr.py::test_vs_oracle
+            v['ok'] = v['max_rel_err_vs_oracle'] <= v['tol']
+            v['same_deflation_order_frac'] = float(np.mean(np.abs(got - ref).max(-1) <= 8e-6 * np.abs(ref).max()))
+            return v
+        w.check = check
 
         def cpu(budget_s):
             import oracle as O
@@ -152,9 +288,20 @@ def make_workload(name, n_arg, device, rank, layout):
         w.units, w.bytes_per_unit, w.dtype = n, 2 * 64 * 8, 'f64'
         w.desc = f'batchinv 8x8 general fp64, batch {n:.0e}'
         w.metric, w.unit = '8x8 fp64 inversions/sec', 'inversions/s'
-        w.step = lambda: N.batchinv(a)
-        w.kernel = 'rec_kernel<double, BatchInvOp<double, 8>>'
-        w.check = lambda: (0.0, True)
+        last = {}
+
+        def step():
+            last['out'] = N.batchinv(a)
+        w.step = step
+        w.kernel = 'rec_kernel<double, BatchInvOp<double, 8>, 1>'
+
+        def check():
+            import oracle as O
+            idx = head_tail(n).to(device)
+            # Gauss-Jordan in registers vs the oracle's LU: same pivots, different summation order
+            return verdict(last['out'][idx].cpu().numpy(), O.batch_inv(a[idx].cpu().numpy()), 'f64',
+                           f'first 1e6 + last 1e5 of {n:.0e} matrices')
+        w.check = check
 
         def cpu(budget_s):
             import oracle as O
@@ -175,9 +322,32 @@ def make_workload(name, n_arg, device, rank, layout):
         w.desc = f'reduce.{name} over {n * 4 / 2 ** 30:.0f} GiB fp32, 1% NaN'
         w.metric, w.unit = f'{name} elements/sec', 'elements/s'
         fn = N.reduce.nansum if name == 'nansum' else N.reduce.nanmax
-        w.step = lambda: fn(x)
+        last = {}
+
+        def step():
+            last['out'] = fn(x)
+        w.step = step
         w.kernel = f'reduce_all_k1<float, {0 if name == "nansum" else 1}>'
-        w.check = lambda: (0.0, True)
+
+        def check():
+            # the output is ONE scalar over the whole tensor, so the oracle has to see all of it:
+            # streamed to the host in 1 GiB chunks, reduced there by the C oracle (float64 accumulation)
+            import numpy as np
+            import oracle as O
+            got = float(last['out'])
+            tot, tot_abs, mx = 0.0, 0.0, -np.inf
+            for lo in range(0, n, chunk):
+                x_h = x[lo:min(n, lo + chunk)].cpu().numpy()
+                if name == 'nansum':
+                    tot += float(O.reduce('nansum', x_h, out_f64=True))
+                    tot_abs += float(O.reduce('nansum', np.abs(x_h), out_f64=True))
+                else:
+                    mx = max(mx, float(O.reduce('nanmax', x_h)))
+            what = f'the whole tensor ({n:.3g} elements, chunked float64 oracle)'
+            if name == 'nansum':     # |s - s64| / sum|x| <= 1e-6
+                return verdict(np.float64(got), np.float64(tot), 'f32', what, scale=tot_abs)
+            return verdict(np.float32(got), np.float32(mx), 'f32', what, exact_expected=True)
+        w.check = check
 
         def cpu(budget_s):
             import oracle as O
@@ -215,12 +385,12 @@ def host_cores():
     return cores
 
 
-def time_cpu(fn, units, budget_s):
-    """best-of repeated runs of the oracle within ~budget_s seconds"""
+def time_cpu(fn, units, budget_s, reps_min=2):
+    """best-of repeated runs within ~budget_s seconds (after one untimed run)"""
     fn()
     best, t_end = float('inf'), time.time() + budget_s
     reps = 0
-    while time.time() < t_end or reps < 2:
+    while time.time() < t_end or reps < reps_min:
         t0 = time.perf_counter()
         fn()
         best = min(best, time.perf_counter() - t0)
@@ -228,46 +398,118 @@ def time_cpu(fn, units, budget_s):
     return units / best
 
 
-def main():
-    a = parse()
+def stored_traffic(workload, units, layout):
+    """PMC traffic per launch from the committed rocprofv3 --pmc passes (profiles/traffic_*.json).
+    It is a STORED measurement, not taken in this run, and is reported only when this run's
+    batch and layout are the ones the counters were collected on."""
+    path = os.path.join(ROOT, 'profiles', f'traffic_{workload}.json')
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, None
+    if int(rec.get('units', -1)) != int(units) or rec.get('layout', 'aos') != layout:
+        return None, f'profiles/traffic_{workload}.json holds a different batch/layout; not reported'
+    return rec.get('hbm_bytes_per_launch'), f'profiles/traffic_{workload}.json (stored rocprofv3 --pmc pass, not this run)'
+
+
+def census(world, device, dist):
+    """every rank contributes one count and its device identity: proves N ranks on N distinct GPUs"""
+    import torch
+    if device.type == 'cuda':
+        p = torch.cuda.get_device_properties(device)
+        ident = {'rank': int(os.environ.get('RANK', '0')), 'index': device.index,
+                 'name': p.name, 'uuid': str(getattr(p, 'uuid', '')),
+                 'pci': '%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), getattr(p, 'pci_bus_id', 0),
+                                            getattr(p, 'pci_device_id', 0))}
+    else:
+        ident = {'rank': int(os.environ.get('RANK', '0')), 'index': None, 'name': 'cpu', 'uuid': '', 'pci': ''}
+    if world == 1:
+        return 1, [ident]
+    ones = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(ones)
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    return int(ones.item()), idents
+
+
+def run_rank(a):
     import torch
     import torch.distributed as dist
-    from nitorch_fastmath_amd.shard import max_over_ranks
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus != world:
+        print(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as '
+              f'{a.gpus} GPUs (launch with --nproc-per-node {a.gpus}, or unset WORLD_SIZE and let bench.py '
+              f'start the ranks)', file=sys.stderr)
+        return 2
+    on_gpu = a.backend == 'nccl'
+    if not on_gpu and a.workload != 'null':
+        print('bench.py: --backend gloo only runs the launcher self-test (--workload null); '
+              'the product has no CPU path', file=sys.stderr)
+        return 2
+    if on_gpu:
+        from nitorch_fastmath_amd.shard import max_over_ranks
+        device = torch.device('cuda', local_rank if world > 1 else 0)
+        torch.cuda.set_device(device)
+    else:
+        from nitorch_fastmath_amd.shard import max_over_ranks
+        device = torch.device('cpu')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f'warning: --gpus {a.gpus} but WORLD_SIZE {world}', file=sys.stderr)
-    device = torch.device('cuda', local_rank if world > 1 else 0)
-    torch.cuda.set_device(device)
+        if on_gpu:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     w = make_workload(a.workload, a.n, device, rank, a.layout)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def event():
+        if not on_gpu:
+            return time.perf_counter()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                      # torch's current stream = the stream the kernels are launched on
+        return e
+
+    def elapsed_ms(e0, e1):
+        return (e1 - e0) * 1e3 if not on_gpu else e0.elapsed_time(e1)
 
     for _ in range(a.warmup):
         w.step()
+    settle_steps = 0
+    if a.settle_ms > 0 and on_gpu:
+        sync()
+        t_end = time.perf_counter() + a.settle_ms * 1e-3
+        while time.perf_counter() < t_end and settle_steps < 10000:
+            for _ in range(4):
+                w.step()
+            sync()
+            settle_steps += 4
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = []
     t0 = time.perf_counter()
-    ev0.record()                       # same stream the kernels are launched on
     for _ in range(a.steps):
+        marks.append(event())
         w.step()
-    ev1.record()
+    marks.append(event())
     barrier()
     wall = time.perf_counter() - t0
     wall = max_over_ranks(wall, device=device)
-    kern_ms = ev0.elapsed_time(ev1) / a.steps          # average launch duration on the stream
+    per_step = sorted(elapsed_ms(marks[i], marks[i + 1]) for i in range(a.steps))
+    kern_ms = elapsed_ms(marks[0], marks[-1]) / a.steps      # average launch duration on the stream
+    median_ms, min_ms = per_step[len(per_step) // 2], per_step[0]
+    ranks_seen, devices = census(world, device, dist)
     gather_ms = None
-    if a.gather and getattr(w, 'output', None) is not None and world > 1:
+    if a.gather and w.output is not None and world > 1:
         from nitorch_fastmath_amd.shard import gather_outputs
         barrier()
         tg = time.perf_counter()
@@ -279,52 +521,84 @@ def main():
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return 0
+    rc = 0
+    distinct = len({(d['uuid'], d['pci'], d['index']) for d in devices})
     value = world * w.units * a.steps / wall
-    achieved = w.units * w.bytes_per_unit / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', f'traffic_{a.workload}.json')
-    if os.path.exists(tpath):          # PMC pass result (separate rocprofv3 --pmc runs), per launch
-        try:
-            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
     line = {
         'metric': w.metric, 'value': value, 'unit': w.unit, 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': wall / a.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': w.dtype, 'data': 'synthetic',
         'config': {'workload': w.desc, 'per_gpu_units': w.units, 'parallelism': f'batch-shard x{world}',
-                   'layout': a.layout, 'kernel': w.kernel},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'bytes_per_unit': w.bytes_per_unit, 'kernel_ms': kern_ms,
-                     'frac_of_achievable_6300': achieved / 6300.0},
+                   'layout': a.layout, 'kernel': w.kernel, 'settle_steps': settle_steps,
+                   'launcher': 'bench.py (self-launched ranks)' if os.environ.get('NFM_BENCH_SELF_LAUNCHED')
+                   else ('external (WORLD_SIZE in env)' if world > 1 else 'single process')},
+        'ranks_seen': ranks_seen, 'distinct_devices': distinct, 'devices': devices,
     }
+    if ranks_seen != world or (on_gpu and distinct != world):
+        print(f'bench.py: census mismatch: {ranks_seen} ranks on {distinct} distinct devices for world {world}',
+              file=sys.stderr)
+        rc = 3
+    if w.bytes_per_unit:
+        achieved = w.units * w.bytes_per_unit / (kern_ms * 1e-3) / 1e9
+        traffic, source = stored_traffic(a.workload, w.units, a.layout)
+        line['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': source,
+                            'bytes_per_unit': w.bytes_per_unit, 'kernel_ms': kern_ms,
+                            'kernel_ms_median': median_ms, 'kernel_ms_min': min_ms,
+                            'frac_at_median': w.units * w.bytes_per_unit / (median_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            'frac_at_min': w.units * w.bytes_per_unit / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            'frac_of_achievable_6300': achieved / 6300.0}
     if gather_ms is not None:
         line['gather_ms'] = gather_ms   # optional xGMI all-gather of the outputs, outside `value`
-    if world == 1 and not a.no_cpu:
-        # the CPU leg (rank 0, one GPU only): the oracle is timed as the baseline and, while it is
-        # loaded, checks a sample of the GPU output of the last timed step
+    if world == 1 and not a.no_cpu and w.check is not None:
+        # the CPU leg (rank 0, one GPU only): the oracle checks the output of the LAST TIMED STEP,
+        # then is timed as the baseline
         import oracle as O
         O.build()
-        err, exact = w.check()
-        line['parity'] = {'max_rel_err_vs_oracle': err, 'bit_exact_vs_oracle': exact}
         avail = host_cores()
+        O.set_num_threads(avail)
+        line['parity'] = w.check()
+        if not line['parity']['ok']:
+            print('bench.py: PARITY FAILED against the oracle', file=sys.stderr)
+            rc = 4
         best = None
         # a one-GPU box owns a share of the host (16 threads by the pool's rule); try that
         # and everything visible, keep the faster, report the thread count actually used
         for cores in sorted({min(16, avail), avail}):
             O.set_num_threads(cores)
-            rate, sample = w.cpu(6.0)
+            rate, sample = w.cpu(4.0)
             if best is None or rate > best[0]:
                 best = (rate, cores, sample)
         line['cpu_baseline'] = {'value': best[0], 'unit': w.unit, 'cores': best[1], 'kind': 'port',
-                                'sample': best[2] + ' (C/OpenMP oracle, best of repeated runs, ~6 s per thread count)',
+                                'sample': best[2] + ' (C/OpenMP oracle, best of repeated runs, ~4 s per thread count)',
                                 'host_threads_visible': avail}
-    print(json.dumps(line))
+        if w.cpu_eager is not None:
+            # the reference's own cost shape (component-first, ~270 full-batch ATen ops with n-sized
+            # temporaries per 4x4 solve), restated in eager torch: 1 thread and all threads
+            from oracle import torch_eager as T
+            r1, n1 = w.cpu_eager(1, 2_000_000)
+            ra, na = w.cpu_eager(avail, 10_000_000)
+            line['cpu_baseline']['torch_eager'] = {
+                'k1': r1, 'kall': ra, 'cores_all': avail, 'unit': w.unit, 'ops_per_call': T.ops_per_call(4),
+                'sample': f'first {n1:.0e} (1 thread) / {na:.0e} ({avail} threads) systems, best of 1 run after warm-up',
+                'note': 'oracle/torch_eager.py: eager restatement of the reference CPU op sequence, pinned to tests/golden'}
+    print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus < 1:
+        print('bench.py: --gpus must be >= 1', file=sys.stderr)
+        return 2
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(a, argv)
+    return run_rank(a)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

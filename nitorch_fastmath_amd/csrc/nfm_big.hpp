@@ -286,11 +286,10 @@ int big_lu_launch(const BigArgs &g, int64_t no, int64_t ni, void *stream)
 {
     if (no == 0 || ni == 0) return NFM_OK;
     const size_t lds = (size_t)(g.N * g.N + 2 * g.N) * kWave * sizeof(T);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&big_lu_kernel<T, OP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+    if (lds > 64 * 1024) { // opt-in per kernel and per device (lds_opt_in, nfm_common.hpp)
+        static std::atomic<uint64_t> have{0};
+        const int rc = lds_opt_in(have, reinterpret_cast<const void *>(&big_lu_kernel<T, OP>), 160 * 1024);
+        if (rc != NFM_OK) return rc;
     }
     dim3 grid((unsigned)((ni + kWave - 1) / kWave), (unsigned)no, 1);
     hipLaunchKernelGGL((big_lu_kernel<T, OP>), grid, dim3(kWave), lds, static_cast<hipStream_t>(stream), g);

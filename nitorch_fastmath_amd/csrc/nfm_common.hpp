@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/nfm_hip.h"
 
 namespace nfm {
@@ -457,6 +458,25 @@ inline int launch_status()
 {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? NFM_OK : (int)e;
+}
+
+// More than 64 KiB of dynamic LDS needs an opt-in (hipFuncSetAttribute) per kernel function AND
+// per device: the attribute lives in the device's copy of the code object.  `mask` is the
+// kernel's own record of the devices that already have it (bit d = device d; devices >= 64 are
+// never recorded and simply re-apply it).  Keyed on the CURRENT device of the calling thread,
+// lock-free, and idempotent when two host threads race (both set the same value).  The HIP
+// status is propagated: a failed opt-in must not be followed by a launch that needs it.
+inline int lds_opt_in(std::atomic<uint64_t> &mask, const void *kernel, size_t bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && ((mask.load(std::memory_order_acquire) >> dev) & 1u)) return NFM_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    if (tracked) mask.fetch_or(uint64_t(1) << dev, std::memory_order_release);
+    return NFM_OK;
 }
 
 // pick the number of lanes per workgroup so that the LDS image stays <= ~32 KiB

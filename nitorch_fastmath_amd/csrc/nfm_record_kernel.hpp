@@ -424,17 +424,21 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
     dim3 grid((unsigned)nblk, (unsigned)n_outer, 1), block(tile, 1, 1);
     const size_t lds = any ? (size_t)L::gtotal : 0;
-    static bool attr_done = false; // > 64 KiB dynamic LDS needs an opt-in, once per kernel
-    if ((L::gtotal > 64 * 1024 || LF::total > 64 * 1024) && !attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_AOS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LF::total);
-        if constexpr (!FAST_ONLY) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_ANY>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_SOA>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, L::gtotal);
+    // > 64 KiB of dynamic LDS: opt-in per kernel and per device (lds_opt_in, nfm_common.hpp)
+    if (fast) {
+        if (LF::total > 64 * 1024) {
+            static std::atomic<uint64_t> have_aos{0};
+            const int rc = lds_opt_in(have_aos, reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_AOS>), LF::total);
+            if (rc != NFM_OK) return rc;
         }
-        attr_done = true;
+    } else if (L::gtotal > 64 * 1024) {
+        if constexpr (!FAST_ONLY) {
+            static std::atomic<uint64_t> have_any{0}, have_soa{0};
+            int rc = lds_opt_in(have_any, reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_ANY>), L::gtotal);
+            if (rc == NFM_OK)
+                rc = lds_opt_in(have_soa, reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_SOA>), L::gtotal);
+            if (rc != NFM_OK) return rc;
+        }
     }
     if (fast) {
         hipLaunchKernelGGL((rec_kernel<T, Op, KIND_AOS>), grid, block, (size_t)LF::total,
@@ -465,11 +469,11 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
             if (sfast && wide) {
                 if constexpr (TILE_W != Op::TILE) {
                     using LW = RecLayout<T, Op, TILE_W>;
-                    static bool attr_w = false;
-                    if (LW::gtotal > 64 * 1024 && !attr_w) {
-                        hipFuncSetAttribute(reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_SOAW>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LW::gtotal);
-                        attr_w = true;
+                    if (LW::gtotal > 64 * 1024) {
+                        static std::atomic<uint64_t> have_soaw{0};
+                        const int rc = lds_opt_in(
+                            have_soaw, reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_SOAW>), LW::gtotal);
+                        if (rc != NFM_OK) return rc;
                     }
                     const int64_t nb = (n_inner + TILE_W - 1) / TILE_W;
                     hipLaunchKernelGGL((rec_kernel<T, Op, KIND_SOAW>), dim3((unsigned)nb, (unsigned)n_outer, 1),

@@ -1,25 +1,31 @@
-"""Helpers reached from the hot path (reference `utils.py`): list coercion, linear ->
-sub indices, machine epsilon."""
+"""Helpers reached from the hot path (`ensure_list`, `ind2sub`, `eps` of the
+reference's `utils.py`; its other helpers are not on the path and are not rebuilt), plus
+`graphed` (HIP-graph capture of launch-bound call chains)."""
 from types import GeneratorType as generator
 import torch
-from builtins import max as builtins_max
 
-__all__ = ['ensure_list', 'ind2sub', 'sub2ind', 'eps', 'fast_slice_tensor', 'slice_tensor', 'cumprod',
-           'broadcast_backward', 'graphed']
+__all__ = ['ensure_list', 'ind2sub', 'eps', 'graphed']
 
 
 def ensure_list(x, size=None, crop=True, **kwargs):
-    """Ensure that an object is a list (of size at least `size`) -- `utils.py:11-28`."""
-    if not isinstance(x, (list, tuple, range, generator)):
-        x = [x]
-    elif not isinstance(x, list):
-        x = list(x)
-    if size and len(x) < size:
-        default = kwargs.get('default', x[-1])
-        x += [default] * (size - len(x))
-    if size and crop:
-        x = x[:size]
-    return x
+    """Coerce `x` to a list; with `size`, pad it to at least `size` items (with `default=` or,
+    by default, its last item) and, unless `crop=False`, cut it to exactly `size`.
+    Same contract as the reference helper (`utils.py:11-28`): scalars and other non-sequences
+    become one-item lists; lists are padded in place, tuples / ranges / generators are copied."""
+    if isinstance(x, list):
+        items = x
+    elif isinstance(x, (tuple, range, generator)):
+        items = list(x)
+    else:
+        items = [x]
+    if size:
+        missing = size - len(items)
+        if missing > 0:
+            fill = kwargs['default'] if 'default' in kwargs else items[-1]
+            items.extend([fill] * missing)
+        if crop:
+            items = items[:size]
+    return items
 
 
 def _strides(shape):
@@ -41,15 +47,6 @@ def ind2sub(ind, shape, out=None):
     return sub
 
 
-def sub2ind(subs, shape, out=None):
-    """Sub indices `(D, ...)` -> linear indices (`utils.py:148-178`)."""
-    subs = [torch.as_tensor(s) for s in subs]
-    ind = torch.zeros_like(subs[-1]) if out is None else out.zero_()
-    for s, st in zip(subs, _strides(shape)):
-        ind += s * st
-    return ind
-
-
 def eps(dtype='float32'):
     """Machine epsilon table of the reference (`utils.py:232-249`)."""
     if dtype in ('float16', torch.float16, 'complex32', getattr(torch, 'complex32', None)):
@@ -59,64 +56,6 @@ def eps(dtype='float32'):
     if dtype in ('float64', torch.float64, 'complex128', torch.complex128):
         return 2 ** -52
     raise NotImplementedError
-
-
-def fast_slice_tensor(x, index, dim=-1):
-    """`x[..., index, ...]` along one dim with native indexing: a view when `index` is a slice or int
-    (`utils.py:30-57`)."""
-    key = [slice(None)] * x.dim()
-    key[dim] = index
-    return x[tuple(key)]
-
-
-def slice_tensor(x, index, dim=None):
-    """Native indexing along one or several dims (`utils.py:60-108`): `index` is one index or a
-    tuple of indices (ints, lists, slices, long tensors; no ellipsis, no masks), `dim` the dims they
-    apply to (default: the last `len(index)` dims)."""
-    if not isinstance(index, tuple):
-        index = (index,)
-    dims = list(range(-len(index), 0)) if dim is None else ensure_list(dim)
-    n = builtins_max(len(index), len(dims))
-    dims, index = ensure_list(dims, n), ensure_list(list(index), n)
-    key = [slice(None)] * x.dim()
-    for d, ind in zip(dims, index):
-        if ind is Ellipsis or (torch.is_tensor(ind) and ind.dtype == torch.bool):
-            raise TypeError('`index` cannot be an ellipsis or mask')
-        key[d] = ind
-    return x[tuple(key)]
-
-
-def cumprod(sequence, reverse=False, exclusive=False):
-    """Cumulative product of a sequence as a list (`utils.py:111-145`):
-    `reverse`: right to left, `[a*b*c, b*c, c]`; `exclusive`: shifted, `[1, a, a*b]`."""
-    items = list(sequence)
-    if reverse:
-        items.reverse()
-    out, acc = [], None
-    for e in items:
-        acc = e if acc is None else acc * e
-        out.append(acc)
-    if exclusive:
-        out = [1] + out[:-1]
-    if reverse:
-        out.reverse()
-    return out
-
-
-def broadcast_backward(input, shape):
-    """Sum a broadcast tensor back to the original `shape` (`utils.py:252-279`)."""
-    shape = tuple(shape)
-    lead = input.dim() - len(shape)
-    if lead < 0:
-        raise ValueError(f'Shapes not compatible for broadcast: {tuple(input.shape)} and {shape}')
-    for k, s in enumerate(shape):
-        if s != input.shape[lead + k]:
-            if s != 1:
-                raise ValueError(f'Shapes not compatible for broadcast: {tuple(input.shape)} and {shape}')
-            input = input.sum(dim=lead + k, keepdim=True)
-    if lead:
-        input = input.sum(dim=list(range(lead)))
-    return input
 
 
 class graphed:

@@ -11,7 +11,7 @@ for w in sym_solve6 batchinv8 nansum nanmax; do
   done
 done
 cd $R
-python scripts/parse_pmc.py $O/pmc2_sym_solve6_FETCH_SIZE $O/pmc2_sym_solve6_WRITE_SIZE "SolveOp<float, 6, 0>" $O/traffic_sym_solve6.json sym_solve6 | cut -c1-160
-python scripts/parse_pmc.py $O/pmc2_batchinv8_FETCH_SIZE $O/pmc2_batchinv8_WRITE_SIZE "BatchInvOp<double, 8>" $O/traffic_batchinv8.json batchinv8 | cut -c1-160
-python scripts/parse_pmc.py $O/pmc2_nansum_FETCH_SIZE $O/pmc2_nansum_WRITE_SIZE "reduce_all_k1<float, 0>" $O/traffic_nansum.json nansum | cut -c1-160
-python scripts/parse_pmc.py $O/pmc2_nanmax_FETCH_SIZE $O/pmc2_nanmax_WRITE_SIZE "reduce_all_k1<float, 1>" $O/traffic_nanmax.json nanmax | cut -c1-160
+python scripts/parse_pmc.py $O/pmc2_sym_solve6_FETCH_SIZE $O/pmc2_sym_solve6_WRITE_SIZE "SolveOp<float, 6, 0>" $O/traffic_sym_solve6.json sym_solve6 1e8 aos | cut -c1-160
+python scripts/parse_pmc.py $O/pmc2_batchinv8_FETCH_SIZE $O/pmc2_batchinv8_WRITE_SIZE "BatchInvOp<double, 8>" $O/traffic_batchinv8.json batchinv8 1e7 aos | cut -c1-160
+python scripts/parse_pmc.py $O/pmc2_nansum_FETCH_SIZE $O/pmc2_nansum_WRITE_SIZE "reduce_all_k1<float, 0>" $O/traffic_nansum.json nansum 8589934592 aos | cut -c1-160
+python scripts/parse_pmc.py $O/pmc2_nanmax_FETCH_SIZE $O/pmc2_nanmax_WRITE_SIZE "reduce_all_k1<float, 1>" $O/traffic_nanmax.json nanmax 8589934592 aos | cut -c1-160

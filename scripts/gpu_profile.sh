@@ -14,7 +14,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
 ls $O/pmc_${TAG}_fetch/* | head
 cd $R
-python scripts/parse_pmc.py $O/pmc_${TAG}_fetch $O/pmc_${TAG}_write "SolveOp<float, 4, 0>" $O/traffic_sym_solve4.json sym_solve4
+python scripts/parse_pmc.py $O/pmc_${TAG}_fetch $O/pmc_${TAG}_write "SolveOp<float, 4, 0>" $O/traffic_sym_solve4.json sym_solve4 1e8 aos
 for w in sym_solve4 sym_solve6 batchinv8 sym_invert3 nansum nanmax; do
   timeout -k 10 400 python bench.py --steps 100 --warmup 10 --workload $w > $O/bench_${TAG}_$w.log 2>&1; echo "bench $w rc=$?"; tail -1 $O/bench_${TAG}_$w.log | cut -c1-330
 done

@@ -168,7 +168,6 @@ def test_mat_kind_and_utils():
     ind = torch.tensor([0, 5, 23])
     sub = utils.ind2sub(ind, [2, 3, 4])
     assert sub.tolist() == np.array(np.unravel_index([0, 5, 23], (2, 3, 4))).tolist()
-    assert utils.sub2ind(list(sub), [2, 3, 4]).tolist() == [0, 5, 23]
     assert utils.ensure_list(3, 2) == [3, 3] and utils.ensure_list((1, 2)) == [1, 2]
     assert utils.eps(torch.float32) == 2 ** -23 and utils.eps('float64') == 2 ** -52
     x = torch.zeros(3, 6)
