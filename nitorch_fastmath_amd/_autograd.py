@@ -129,9 +129,10 @@ class EigSymFn(torch.autograd.Function):
     A_bar = U (diag(D_bar) + F o (U^T U_bar)) U^T, F_ij = 1 / (d_j - d_i), F_ii = 0."""
 
     @staticmethod
-    def forward(ctx, a, compute_u, upper, max_iter, tol):
+    def forward(ctx, a, compute_u, upper, max_iter, tol, arithmetic='fast'):
         from . import qr
-        val, vec = qr.eig_sym(a, compute_u=True, upper=upper, check_finite=False, max_iter=max_iter, tol=tol)
+        val, vec = qr.eig_sym(a, compute_u=True, upper=upper, check_finite=False, max_iter=max_iter, tol=tol,
+                              arithmetic=arithmetic)
         val, vec = val.contiguous(), vec.contiguous()
         ctx.save_for_backward(val, vec)
         ctx.set_materialize_grads(False)
@@ -145,18 +146,18 @@ class EigSymFn(torch.autograd.Function):
         from . import sym
         D, U = ctx.saved_tensors
         if gD is None and gU is None:
-            return (None,) * 5
+            return (None,) * 6
         n = D.shape[-1]
         if gU is None:
             # U diag(gD) U^T = J^T H J with J = U^T, H = diag(gD): one compact kernel + expansion
-            return sym.sym_to_full(sym.sym_matmul(U.transpose(-1, -2), gD.contiguous())), None, None, None, None
+            return sym.sym_to_full(sym.sym_matmul(U.transpose(-1, -2), gD.contiguous())), None, None, None, None, None
         # eigenvector term (small dense products per matrix; element-wise glue in torch)
         F = D.unsqueeze(-2) - D.unsqueeze(-1)                     # F_ij = d_j - d_i
         F = torch.where(F == 0, torch.zeros_like(F), 1 / F)
         inner = F * _small_matmul(U.transpose(-1, -2), gU)
         if gD is not None:
             inner = inner + torch.diag_embed(gD)
-        return _small_matmul(_small_matmul(U, inner), U.transpose(-1, -2)), None, None, None, None
+        return _small_matmul(_small_matmul(U, inner), U.transpose(-1, -2)), None, None, None, None, None
 
 
 def _small_matmul(a, b):

@@ -5,6 +5,7 @@
 #include "nfm_batched_ops.hpp"
 #include "nfm_big.hpp"
 #include "nfm_large.hpp"
+#include "nfm_rowwave.hpp"
 
 namespace nfm {
 
@@ -32,6 +33,10 @@ static int batch_inv_t(int N, int flags, int64_t no, int64_t ni, const nfm_opera
                        void *stream)
 {
     if (N > 8) {
+        if (no == 1 && rowwave_first<T>(N, RWW_INV_GEN)) { // one matrix per 16 lanes (nfm_rowwave.hip)
+            const int rc = RowWave<T>::batch_inv(N, ni, a, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         if (no == 1) {
             const int rc = Large<T>::batch_inv(N, ni, a, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
@@ -47,6 +52,10 @@ template <typename T>
 static int batch_det_t(int N, int64_t no, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
     if (N > 8) {
+        if (no == 1 && rowwave_first<T>(N, RWW_DET_GEN)) {
+            const int rc = RowWave<T>::batch_det(N, ni, a, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         if (no == 1) {
             const int rc = Large<T>::batch_det(N, ni, a, out, stream);
             if (rc != NFM_EFALLBACK) return rc;

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include "../../include/nfm_hip.h"
 
@@ -46,14 +47,21 @@ struct Opnd {
 
 template <typename T>
 struct VecOf;
+// `gtype` is the same 16-byte vector with ELEMENT alignment: what global memory is accessed
+// through.  gfx950 executes global_load/store_dwordx4 at any dword-aligned address (the compiler
+// emits the same instruction for both types), so a contiguous operand whose base sits at an odd
+// element offset inside a 16-byte line -- x[1:], a field carved out of a larger buffer -- streams
+// through the same wide accesses as an aligned one; only LDS keeps the 16-byte alignment.
 template <>
 struct VecOf<float> {
     typedef float type __attribute__((ext_vector_type(4)));
+    typedef float gtype __attribute__((ext_vector_type(4), aligned(4)));
     static constexpr int N = 4;
 };
 template <>
 struct VecOf<double> {
     typedef double type __attribute__((ext_vector_type(2)));
+    typedef double gtype __attribute__((ext_vector_type(2), aligned(8)));
     static constexpr int N = 2;
 };
 
@@ -79,6 +87,7 @@ __host__ __device__ constexpr int sym_idx(int M, int i, int j)
 template <typename T, int C, int TILE>
 struct TileIO {
     using V = typename VecOf<T>::type;
+    using VG = typename VecOf<T>::gtype; // element-aligned: global side only
     static constexpr int kVec = VecOf<T>::N;
     static constexpr int RB = C * (int)sizeof(T);
     static constexpr bool kWide = (RB % 16) == 0;
@@ -116,7 +125,7 @@ struct TileIO {
             for (int it = 0; it < kIters; ++it) {
                 const int q = tid + it * TILE;
                 if (kNVec % TILE == 0 || q < kNVec)
-                    st.v[it] = NFM_LDG(reinterpret_cast<const V *>(g) + q);
+                    st.v[it] = NFM_LDG(reinterpret_cast<const VG *>(g) + q);
             }
         } else {
 #pragma unroll
@@ -204,8 +213,8 @@ struct TileIO {
             for (int it = 0; it < kIters; ++it) {
                 const int q = tid + it * TILE;
                 if (kNVec % TILE == 0 || q < kNVec) {
-                    V v = *reinterpret_cast<const V *>(lds + lds_off(q));
-                    NFM_STG(v, reinterpret_cast<V *>(g) + q);
+                    const V v = *reinterpret_cast<const V *>(lds + lds_off(q));
+                    NFM_STG(static_cast<VG>(v), reinterpret_cast<VG *>(g) + q);
                 }
             }
         } else {
@@ -386,7 +395,10 @@ inline bool tile_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_
                     size_t elem)
 {
     if (op->ptr == nullptr) return false;
-    if (reinterpret_cast<uintptr_t>(op->ptr) % 16 != 0) return false;
+    // any element-aligned base: the tile's 16-byte global accesses only need dword alignment
+    // (VecOf::gtype); NFM_TILE_ALIGN16=1 restores the old 16-byte requirement (A/B measurements)
+    static const bool align16 = [] { const char *e = getenv("NFM_TILE_ALIGN16"); return e && e[0] == '1'; }();
+    if (reinterpret_cast<uintptr_t>(op->ptr) % (align16 ? 16 : elem) != 0) return false;
     if (n_outer != 1) return false; // the facade collapses contiguous outer levels into one
     if (op->stride_inner != C) return false;
     if (rows > 1) {
@@ -394,7 +406,6 @@ inline bool tile_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_
     } else if (C > 1 && op->stride_col != 1) {
         return false;
     }
-    (void)elem;
     return true;
 }
 

@@ -39,7 +39,8 @@ __device__ __forceinline__ void to_mat(const T (&r)[N * N], T (&a)[N][N], int mi
         }
 }
 
-template <typename T, int N, bool WITH_U>
+// FAST: float32 sweep arithmetic of nfm_qr_core.hpp (FastSweeps); false = reference-order IEEE
+template <typename T, int N, bool WITH_U, bool FAST = false>
 struct EigSymOp {
     using RA = Rec<N, N>;
     using RB = NoRec;
@@ -52,7 +53,7 @@ struct EigSymOp {
     {
         T a[N][N], u[N][N];
         to_mat<T, N>(r, a, p.upper);
-        qr::eig_sym1<T, N, WITH_U>(a, u, N, p.max_iter, p.tol);
+        qr::eig_sym1<T, N, WITH_U, FAST>(a, u, N, p.max_iter, p.tol);
 #pragma unroll
         for (int i = 0; i < N; ++i) o[i] = a[i][i];
         if constexpr (WITH_U) {
@@ -188,7 +189,8 @@ struct GivensOp {
 };
 
 // ---------------------------------------------------------------- generic (run-time n)
-enum { QG_EIG = 0, QG_EIG_U, QG_HESS, QG_HESS_U, QG_HESSSYM, QG_HESSSYM_U, QG_QR, QG_RQ, QG_RQ_U, QG_HH };
+enum { QG_EIG = 0, QG_EIG_U, QG_HESS, QG_HESS_U, QG_HESSSYM, QG_HESSSYM_U, QG_QR, QG_RQ, QG_RQ_U, QG_HH,
+       QG_EIG_FAST, QG_EIG_U_FAST };
 
 template <typename T, int OP>
 __global__ __launch_bounds__(64) void qr_generic_kernel(Opnd a, Opnd b, T *__restrict__ out, int64_t out_rec,
@@ -210,17 +212,19 @@ __global__ __launch_bounds__(64) void qr_generic_kernel(Opnd a, Opnd b, T *__res
         po[n] = alpha;
         return;
     } else {
-    const bool symin = OP == QG_EIG || OP == QG_EIG_U || OP == QG_HESSSYM || OP == QG_HESSSYM_U;
+    constexpr bool EIG = OP == QG_EIG || OP == QG_EIG_U || OP == QG_EIG_FAST || OP == QG_EIG_U_FAST;
+    constexpr bool EIGU = OP == QG_EIG_U || OP == QG_EIG_U_FAST;
+    const bool symin = EIG || OP == QG_HESSSYM || OP == QG_HESSSYM_U;
     for (int r = 0; r < n; ++r)
         for (int c = 0; c < n; ++c) {
             int rr = r, cc = c;
             if (symin && ((p.upper && r > c) || (!p.upper && r < c))) { rr = c; cc = r; }
             m[r][c] = pa[rr * a.sr + cc * a.sc];
         }
-    if constexpr (OP == QG_EIG || OP == QG_EIG_U) {
-        qr::eig_sym1<T, 0, OP == QG_EIG_U>(m, u, n, p.max_iter, p.tol);
+    if constexpr (EIG) {
+        qr::eig_sym1<T, 0, EIGU, OP == QG_EIG_FAST || OP == QG_EIG_U_FAST>(m, u, n, p.max_iter, p.tol);
         for (int r = 0; r < n; ++r) po[r] = m[r][r];
-        if (OP == QG_EIG_U)
+        if (EIGU)
             for (int r = 0; r < n; ++r)
                 for (int c = 0; c < n; ++c) po[n + r * n + c] = u[r][c];
     } else if constexpr (OP == QG_HESS || OP == QG_HESS_U || OP == QG_HESSSYM || OP == QG_HESSSYM_U) {
@@ -347,11 +351,20 @@ static nfm_operand packed_out(void *out, int64_t rec, int64_t ni)
 }
 
 template <typename T>
-static int eig_sym_t(int N, int with_u, int64_t no, int64_t ni, const nfm_operand *a, void *out, const QrParams &p,
-                     void *stream)
+static int eig_sym_t(int N, int with_u, int fast, int64_t no, int64_t ni, const nfm_operand *a, void *out,
+                     const QrParams &p, void *stream)
 {
     const int64_t rec = N + (with_u ? N * N : 0);
     nfm_operand o = packed_out(out, rec, ni);
+    if constexpr (qr::FastSweeps<T>::on) {
+        if (fast && with_u) {
+            NFM_QR_SWITCH8(N, return (rec_launch<T, EigSymOp<T, N, true, true>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+            return qr_generic_launch<T, QG_EIG_U_FAST>(a, nullptr, out, rec, no, ni, p, stream);
+        } else if (fast) {
+            NFM_QR_SWITCH8(N, return (rec_launch<T, EigSymOp<T, N, false, true>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
+            return qr_generic_launch<T, QG_EIG_FAST>(a, nullptr, out, rec, no, ni, p, stream);
+        }
+    }
     if (with_u) {
         NFM_QR_SWITCH8(N, return (rec_launch<T, EigSymOp<T, N, true>>(a, nullptr, nullptr, &o, no, ni, p, stream)))
         return qr_generic_launch<T, QG_EIG_U>(a, nullptr, out, rec, no, ni, p, stream);
@@ -549,16 +562,17 @@ int nfm_qr_rq_hessenberg(int dtype, int N, int sym, int64_t n_outer, int64_t n_i
 #endif
 
 #if NFM_QR_PART == 0
-int nfm_qr_eig_sym(int dtype, int N, int upper, int with_u, int max_iter, double tol, int64_t n_outer,
+int nfm_qr_eig_sym(int dtype, int N, int upper, int flags, int max_iter, double tol, int64_t n_outer,
                    int64_t n_inner, const nfm_operand *a, void *out, void *stream)
 {
     QR_COMMON_CHECKS(N)
-    if (max_iter < 0) return NFM_EINVAL;
+    if (max_iter < 0 || flags < 0 || flags > (NFM_EIG_VECTORS | NFM_EIG_REFERENCE_ORDER)) return NFM_EINVAL;
+    const int with_u = (flags & NFM_EIG_VECTORS) != 0, fast = (flags & NFM_EIG_REFERENCE_ORDER) == 0;
     if ((rc = check_operand(a, dtype, nonempty))) return rc;
     if (nonempty && out == nullptr) return NFM_EINVAL;
     QrParams p = mkparams(N, upper ? 1 : 0, 1, 0, max_iter, tol);
-    return dtype == NFM_F32 ? eig_sym_t<float>(N, with_u, n_outer, n_inner, a, out, p, stream)
-                            : eig_sym_t<double>(N, with_u, n_outer, n_inner, a, out, p, stream);
+    return dtype == NFM_F32 ? eig_sym_t<float>(N, with_u, fast, n_outer, n_inner, a, out, p, stream)
+                            : eig_sym_t<double>(N, with_u, fast, n_outer, n_inner, a, out, p, stream);
 }
 #endif
 

@@ -35,7 +35,72 @@ __device__ __forceinline__ bool finite_(T x)
     return fabs_(x) < __builtin_huge_val() && x == x;
 }
 
+// ---------------------------------------------------------------------------------------
+// Arithmetic policy of the QR SWEEPS of eig_sym (not of the public givens / rq_hessenberg /
+// householder entry points, which keep the reference's operation order and IEEE div / sqrt).
+//
+// IEEE division and square root are software sequences on gfx950 (v_div_scale x2, v_rcp,
+// 4 fma, v_div_fmas, v_div_fixup; v_sqrt + fix-up), a third of the instructions of a sweep.
+// For float32 the sweeps use the hardware approximations instead, refined where the value
+// enters the result: a rotation is (c, s) = (x, -y) * rsqrt(x^2 + y^2) with one Newton step
+// on v_rsq_f32 (relative error <= ~1 ulp, i.e. the same as the reference's sqrt followed by
+// two divisions), products and sums contract to fma (each fma rounds once where the
+// reference rounds twice).  The Wilkinson shift and the convergence ratio only steer the
+// iteration -- ANY shift gives a similarity transform -- so they use v_sqrt_f32 / v_rcp_f32
+// unrefined.  Arguments outside [2^-100, 2^100] (zeros, denormal squares, inf, NaN) take the
+// IEEE path, so the special values behave exactly as before.  float64 keeps the IEEE path:
+// v_rcp_f64 / v_rsq_f64 deliver ~26 bits and two Newton steps cost what the division does.
+//
+// What the fast sweeps change is rounding, not accuracy (measured against numpy.linalg.eigvalsh
+// in float64: within 2x the error of the reference-order arithmetic at every order,
+// profiles/r02/accuracy_eig.md) -- but the ORDER in which the eigenvalues deflate and the SIGNS
+// of the eigenvectors are decided by bits that the rounding moves (for 8x8 one matrix in eight
+// deflates in another order), and two float32 runs that are each 7e-7 accurate can differ by
+// 1.4e-6.  So the reference-order arithmetic stays available (FM = false: bit-identical to the
+// CPU restatement, same order, same signs) and the caller picks: `eig_sym(..., arithmetic=)`.
+// Error model and its tests: tests/test_gpu_qr.py.
+template <typename T>
+struct FastSweeps {
+    static constexpr bool on = false;
+};
+template <>
+struct FastSweeps<float> {
+    static constexpr bool on = true;
+};
+
+__device__ __forceinline__ float rsq_nr(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float h = (0.5f * x) * r;
+    return __builtin_fmaf(r, __builtin_fmaf(-h, r, 0.5f), r); // r (1.5 - 0.5 x r^2)
+}
+
 // _givens_jit :326-334
+template <typename T>
+__device__ __forceinline__ void givens1(T x, T y, T &c, T &s);
+
+// float32 sweep form of the same rotation (policy above)
+__device__ __forceinline__ void givens_fast1(float x, float y, float &c, float &s)
+{
+    const float r2 = __builtin_fmaf(x, x, y * y);
+    if (__builtin_expect(!(r2 > 0x1p-100f && r2 < 0x1p100f), 0)) {
+        givens1<float>(x, y, c, s);
+        return;
+    }
+    const float inv = rsq_nr(r2);
+    // an axis-aligned pair is an exact rotation in the reference (x / |x| = +-1): keep it exact, so
+    // that diagonal / already deflated input comes back bit for bit
+    c = (y == 0.0f) ? __builtin_copysignf(1.0f, x) : x * inv;
+    s = (x == 0.0f) ? -__builtin_copysignf(1.0f, y) : -(y * inv);
+}
+
+__device__ __forceinline__ void rot_fast1(float &a0, float &a1, float c, float s)
+{
+    const float t = s * a0;
+    a0 = __builtin_fmaf(a0, c, -(s * a1));
+    a1 = __builtin_fmaf(a1, c, t);
+}
+
 template <typename T>
 __device__ __forceinline__ void givens1(T x, T y, T &c, T &s)
 {
@@ -229,19 +294,28 @@ __device__ __forceinline__ void qr_hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX
 
 // One R Q step on the leading m x m block; WITH_U also rotates the columns of u (n rows).
 // sym: the tridiagonal shortcut of _rq_hessenberg_jit_ :457-485; otherwise the full ranges.
-template <typename T, int NT, bool WITH_U>
+// FM: float32 sweep arithmetic (FastSweeps above); only eig_sym's sweeps ask for it.
+template <typename T, int NT, bool WITH_U, bool FM = false>
 __device__ __forceinline__ void rq_step1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX],
                                          T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m, bool sym)
 {
     constexpr int MX = Dim<NT>::MAX;
     T lc[MX], ls[MX];
+    auto giv = [](T x, T y, T &c, T &s) {
+        if constexpr (FM) givens_fast1(x, y, c, s);
+        else givens1(x, y, c, s);
+    };
+    auto rot = [](T &a0, T &a1, T c, T s) {
+        if constexpr (FM) rot_fast1(a0, a1, c, s);
+        else rot1(a0, a1, c, s);
+    };
 #pragma unroll
     for (int k = 0; k < MX - 1; ++k) {
         if (k < m - 1) {
-            givens1(a[k][k], a[k + 1][k], lc[k], ls[k]);
+            giv(a[k][k], a[k + 1][k], lc[k], ls[k]);
 #pragma unroll
             for (int j = k; j < MX; ++j)
-                if (j < m && (!sym || j < k + 3)) rot1(a[k][j], a[k + 1][j], lc[k], ls[k]);
+                if (j < m && (!sym || j < k + 3)) rot(a[k][j], a[k + 1][j], lc[k], ls[k]);
         }
     }
 #pragma unroll
@@ -249,11 +323,11 @@ __device__ __forceinline__ void rq_step1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX],
         if (k < m - 1) {
 #pragma unroll
             for (int i = 0; i < k + 2; ++i)
-                if (!sym || i >= k - 1) rot1(a[i][k], a[i][k + 1], lc[k], ls[k]);
+                if (!sym || i >= k - 1) rot(a[i][k], a[i][k + 1], lc[k], ls[k]);
             if (WITH_U) {
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
-                    if (i < n) rot1(u[i][k], u[i][k + 1], lc[k], ls[k]);
+                    if (i < n) rot(u[i][k], u[i][k + 1], lc[k], ls[k]);
             }
         }
     }
@@ -272,13 +346,26 @@ __device__ __forceinline__ T wilkinson1(T h0, T h1, T b)
     return h1 - s * b2 / d;
 }
 
+// the same shift for the float32 sweeps: hardware sqrt / rcp, unrefined (a shift only steers)
+__device__ __forceinline__ float wilkinson_fast1(float h0, float h1, float b)
+{
+    const float b2 = b * b;
+    float d = (h0 - h1) * 0.5f;
+    const float sb2 = (d < 0.0f) ? -b2 : b2;
+    const float t = __builtin_fmaf(d, d, b2);
+    if (__builtin_expect(!(t > 0x1p-100f && t < 0x1p100f), 0)) return wilkinson1<float>(h0, h1, b);
+    d = fabs_(d) + __builtin_amdgcn_sqrtf(t);
+    return h1 - sb2 * __builtin_amdgcn_rcpf(d);
+}
+
 // _qr_explicit(_vectors)_jit_ :572-656 with sym = True; convergence per lane (Q9)
-template <typename T, int NT, bool WITH_U>
+template <typename T, int NT, bool WITH_U, bool FAST = false>
 __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                                              T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int max_iter, double tol)
 {
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
+    constexpr bool FM = FAST && FastSweeps<T>::on;
     if (WITH_U) {
 #pragma unroll
         for (int i = 0; i < MX; ++i)
@@ -290,10 +377,12 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
         if (m <= n) {
             double sos_prev = 0.0;
             for (int it = 0; it < max_iter; ++it) {
-                const T sigma = wilkinson1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
+                T sigma;
+                if constexpr (FM) sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
+                else sigma = wilkinson1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
 #pragma unroll
                 for (int i = 0; i < m; ++i) h[i][i] -= sigma;
-                rq_step1<T, NT, WITH_U>(h, u, n, m, true);
+                rq_step1<T, NT, WITH_U, FM>(h, u, n, m, true);
 #pragma unroll
                 for (int i = 0; i < m; ++i) h[i][i] += sigma;
                 const T bb = fabs_(h[m - 1][m - 2]), a0 = fabs_(h[m - 1][m - 1]), a1 = fabs_(h[m - 2][m - 2]);
@@ -308,7 +397,10 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                 }
                 if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
                     // |prev - new| / prev < tol * 1e-3, written without the fp64 division (prev > 0)
-                    const double sos_new = (double)(sos_lower / sos_diag);
+                    double sos_new;
+                    if constexpr (FM) // the ratio only detects a fixed point of the iteration
+                        sos_new = (double)(sos_lower * __builtin_amdgcn_rcpf(sos_diag));
+                    else sos_new = (double)(sos_lower / sos_diag);
                     const double dif = sos_prev - sos_new;
                     if (sos_prev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sos_prev) break;
                     sos_prev = sos_new;
@@ -342,14 +434,14 @@ __device__ __forceinline__ void reflect_left1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX]
 
 // _fwd_eig_sym :665-681.  `a` holds the symmetric input (the requested triangle already
 // mirrored); on return vals = diagonal, and for WITH_U the columns of u are the eigenvectors.
-template <typename T, int NT, bool WITH_U>
+template <typename T, int NT, bool WITH_U, bool FAST = false>
 __device__ __forceinline__ void eig_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
                                          int n, int max_iter, double tol)
 {
     constexpr int MX = Dim<NT>::MAX;
     T up[MX][MX];
     hessenberg_sym1<T, NT, WITH_U>(a, n, up);
-    qr_explicit1<T, NT, WITH_U>(a, u, n, max_iter, tol);
+    qr_explicit1<T, NT, WITH_U, FAST>(a, u, n, max_iter, tol);
     if (WITH_U) {
         // householder_apply_(u, q, side='left', inverse=True): reflectors in reverse order
 #pragma unroll

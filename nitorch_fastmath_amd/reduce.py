@@ -14,8 +14,11 @@ masked_fill, reduce: `reduce.py:502-510`) and half of it raises on current PyTor
 identity by select, 64-lane wavefront shuffle reduce, double accumulation), and the
 functions that raise upstream implement their documented semantics.
 
-`inplace=True` only ever meant "the input MAY be modified"; this backend never needs
-to, so the flag is accepted and ignored.
+`inplace=True` only ever meant "the input MAY be modified" (`reduce.py:72-74`); the reference
+uses that permission (its `nansum` zeroes, its `nanmax` / `nanmin` write -inf / +inf over, the
+NaNs of the caller's tensor: `reduce.py:502-509`, `:258-260`), this backend never needs to: the
+flag is accepted and the input is left bit-identical (pinned by
+tests/test_gpu_reduce.py::test_inplace_never_modifies_the_input, recorded in INTEGRATION.md).
 '''
 __all__ = [
     'min', 'max', 'nanmin', 'nanmax', 'median',
@@ -275,22 +278,30 @@ def nanmin(input, dim=None, keepdim=False, inplace=False, return_indices=False, 
 
 
 def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_indices=False, out=None):
-    r"""Multi-dimensional median (`reduce.py:384-428`).
+    r"""Multi-dimensional median (`reduce.py:384-428`): the lower of the two middle values for an
+    even count, and the index of the element that holds it.
 
-    Not a streaming reduction and outside the accelerated path: it
-    runs torch's selection kernel on the device, with the reference's multi-dim handling.
+    `omitnan=False` (the default) is what the reference computes: `torch.median`, i.e. a NaN in a
+    slice makes that slice's median NaN -- its docstring says "always omits NaNs" but its code never
+    does (SURVEY quirk Q14; pinned by tests/test_gpu_reduce.py::test_median_semantics).
+    `omitnan=True` is the documented intent: the median of the non-NaN values (all-NaN -> NaN).
+
+    Not a streaming reduction: a selection.  It runs torch's selection kernels on the device with
+    the reference's multi-dim handling and index layout (`(..., len(dim))`, last axis dropped for a
+    scalar `dim`); it is the one function of this module without a kernel in libnfm_hip.so.
     """
     input = torch.as_tensor(input)
     require_gpu(input)
+    fn = torch.nanmedian if omitnan else torch.median
     if dim is None:
-        return _deliver(torch.median(input), out)
+        return _deliver(fn(input), out)
     scalar_dim = not isinstance(dim, (list, tuple, range))
     nd = input.dim()
     dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
     kept = [d for d in range(nd) if d not in dims]
     redshape = [input.shape[d] for d in dims]
     x = input.permute(kept + dims).reshape([input.shape[d] for d in kept] + [-1])
-    val, idx = torch.median(x, dim=-1)
+    val, idx = fn(x, dim=-1)
     if keepdim:
         keptshape = [1 if d in dims else s for d, s in enumerate(input.shape)]
         val, idx = val.reshape(keptshape), idx.reshape(keptshape)

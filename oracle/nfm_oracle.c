@@ -218,8 +218,18 @@ int nfm_oracle_qr_eig_sym(int dtype, int N, int64_t n, int upper, int compute_u,
                           void *vals, void *vecs)
 {
     CHECK_M(N);
-    DISPATCH(nfm_oracle_qr_eig_sym_f32(N, n, upper, compute_u, max_iter, tol, a, vals, vecs),
-             nfm_oracle_qr_eig_sym_f64(N, n, upper, compute_u, max_iter, tol, a, vals, vecs));
+    DISPATCH(nfm_oracle_qr_eig_sym_f32(N, n, upper, compute_u, max_iter, tol, a, vals, vecs, NULL),
+             nfm_oracle_qr_eig_sym_f64(N, n, upper, compute_u, max_iter, tol, a, vals, vecs, NULL));
+}
+
+/* same, also reporting the QR sweeps spent per matrix and per active block size: sweeps (n, N) int32,
+   entry m - 1 = sweeps on the m x m block (the divergence profile of the per-lane GPU kernel) */
+int nfm_oracle_qr_eig_sym_sweeps(int dtype, int N, int64_t n, int upper, int compute_u, int max_iter, double tol,
+                                 void *a, void *vals, void *vecs, int *sweeps)
+{
+    CHECK_M(N);
+    DISPATCH(nfm_oracle_qr_eig_sym_f32(N, n, upper, compute_u, max_iter, tol, a, vals, vecs, sweeps),
+             nfm_oracle_qr_eig_sym_f64(N, n, upper, compute_u, max_iter, tol, a, vals, vecs, sweeps));
 }
 
 int nfm_oracle_version(void) { return 1; }

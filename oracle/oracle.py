@@ -304,11 +304,17 @@ def rq_hessenberg(h, u=None, sym=False, true_rq=True):
     return h if u is None else (h, u)
 
 
-def eig_sym(a, compute_u=False, upper=True, max_iter=1024, tol=1e-32):
+def eig_sym(a, compute_u=False, upper=True, max_iter=1024, tol=1e-32, return_sweeps=False):
     a = np.array(a, copy=True, order='C')
     N = a.shape[-1]
     vals = np.empty(a.shape[:-1], a.dtype)
     vecs = np.empty_like(a) if compute_u else None
+    if return_sweeps:   # (..., N) int32: QR sweeps per active block size m (index m - 1)
+        sweeps = np.zeros(a.shape[:-1], np.int32)
+        _chk(lib().nfm_oracle_qr_eig_sym_sweeps(_dt(a), N, ctypes.c_int64(_nb(a, 2)), int(upper), int(compute_u),
+                                                int(max_iter), ctypes.c_double(tol), _p(a), _p(vals), _p(vecs),
+                                                _p(sweeps)))
+        return ((vals, vecs) if compute_u else vals), sweeps
     _chk(lib().nfm_oracle_qr_eig_sym(_dt(a), N, ctypes.c_int64(_nb(a, 2)), int(upper), int(compute_u), int(max_iter),
                                      ctypes.c_double(tol), _p(a), _p(vals), _p(vecs)))
     return (vals, vecs) if compute_u else vals

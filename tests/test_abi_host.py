@@ -216,7 +216,9 @@ def test_signatures_match_the_reference():
     assert names(N.sym.sym_invert)[:2] == ['mat', 'diag']                       # _impl/sym.py:455
     assert names(N.sym.sym_matvec)[:2] == ['mat', 'vec']                        # _impl/sym.py:134
     assert names(N.batched.batchinv)[0] == 'a' and names(N.batched.batchmatvec) == ['mat', 'vec']
-    assert names(N.qr.eig_sym) == ['a', 'compute_u', 'upper', 'inplace', 'check_finite', 'max_iter', 'tol']   # qr.py:30-38
+    # qr.py:30-38; `arithmetic` is a keyword-only extension (float32 sweep arithmetic, qr.py docstring)
+    assert names(N.qr.eig_sym) == ['a', 'compute_u', 'upper', 'inplace', 'check_finite', 'max_iter', 'tol', 'arithmetic']
+    assert inspect.signature(N.qr.eig_sym).parameters['arithmetic'].kind is inspect.Parameter.KEYWORD_ONLY
     assert names(N.qr.hessenberg_sym) == ['a', 'upper', 'fill', 'inplace', 'check_finite', 'compute_u']        # qr.py:226-233
     assert names(N.qr.householder) == ['x', 'basis', 'inplace', 'check_finite', 'return_alpha']               # qr.py:278-284
     assert names(N.qr.householder_apply) == ['a', 'u', 'k', 'side', 'inverse', 'inplace', 'check_finite']     # qr.py:330-338

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
-from conftest import TOL, relerr, GOLDEN
+from conftest import TOL, EPS, relerr, GOLDEN, parity_ok, within_model
 
 pytestmark = pytest.mark.gpu
 QR_NS = (1, 2, 3, 4, 5, 6, 8, 12)
@@ -24,8 +24,52 @@ def n_(x):
     return x.cpu().numpy()
 
 
-def qr_tol(dn, n):
-    return TOL[dn] * max(1.0, n * n / 4.0)
+class GpuQ:
+    """the QR family on the GPU behind the oracle's call shapes (numpy in, numpy out), so that
+    the golden cases of tests/test_oracle_golden.py run unchanged against the kernels"""
+
+    def __init__(self, dev, arithmetic='reference'):
+        self.dev, self.arithmetic = dev, arithmetic
+
+    def t(self, x):
+        return t(x, self.dev)
+
+    def householder(self, v, basis=0):
+        u, al = Q().householder(self.t(v), basis=basis, return_alpha=True)
+        return n_(u), n_(al)
+
+    def householder_apply(self, a, u, side='both', inverse=False):
+        u = [self.t(x) for x in u] if isinstance(u, list) else self.t(u)
+        return n_(Q().householder_apply(self.t(a), u, side=side, inverse=inverse))
+
+    def givens_apply(self, a, c, s, i=0, j=None, side='both'):
+        if j is None:
+            return n_(Q().givens_apply(self.t(a), self.t(c), self.t(s), i, side=side))
+        return n_(Q().givens_apply(self.t(a), self.t(c), self.t(s), i, j, side=side))
+
+    def hessenberg(self, a, compute_u=False):
+        if compute_u:
+            h, us = Q().hessenberg(self.t(a), compute_u=True)
+            return n_(h), [n_(x) for x in us]
+        return n_(Q().hessenberg(self.t(a)))
+
+    def hessenberg_sym(self, a, upper=True, fill=True, compute_u=False):
+        r = Q().hessenberg_sym(self.t(a), upper=upper, compute_u=compute_u)
+        return (n_(r[0]), [n_(x) for x in r[1]]) if compute_u else n_(r)
+
+    def qr_hessenberg(self, h):
+        q, r = Q().qr_hessenberg(self.t(h))
+        return n_(q), n_(r)
+
+    def rq_hessenberg(self, h, u=None):
+        if u is None:
+            return n_(Q().rq_hessenberg(self.t(h)))
+        h2, u2 = Q().rq_hessenberg(self.t(h), self.t(u))
+        return n_(h2), n_(u2)
+
+    def eig_sym(self, a, compute_u=False, upper=True):
+        r = Q().eig_sym(self.t(a), compute_u=compute_u, upper=upper, arithmetic=self.arithmetic)
+        return (n_(r[0]), n_(r[1])) if compute_u else n_(r)
 
 
 @pytest.fixture(scope='module')
@@ -43,89 +87,93 @@ def test_golden_givens(dev, golden_qr, dn):
 
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 @pytest.mark.parametrize('n', QR_NS)
-def test_golden_family(dev, golden_qr, dn, n):
-    g, k, tol = golden_qr, f'{dn}_n{n}_', qr_tol(dn, n)
-    a, v = t(g[k + 'a'], dev), t(g[k + 'hh_x'], dev)
-    for b in sorted({0, n - 1}):
-        u, al = Q().householder(v, basis=b, return_alpha=True)
-        assert relerr(n_(u), g[k + f'hh_u_b{b}']) <= tol and relerr(n_(al), g[k + f'hh_alpha_b{b}']) <= tol
-        assert not torch.isnan(u).any()
-    u = Q().householder(v)
-    for side in ('left', 'right', 'both'):
-        assert relerr(n_(Q().householder_apply(a, u, side=side)), g[k + f'hh_apply_{side}']) <= tol
-    if n >= 3:
-        u2 = Q().householder(v[:, 1:])
-        assert relerr(n_(Q().householder_apply(a, u2, side='both')), g[k + 'hh_apply_short']) <= tol
-        r = Q().householder_apply(a, [u, u2], side='left', inverse=True)
-        assert relerr(n_(r), g[k + 'hh_apply_two_inv']) <= tol
-    if n >= 2:
-        cc, ss = t(g[k + 'ga_c'], dev)[:, None], t(g[k + 'ga_s'], dev)[:, None]
-        for side in ('left', 'right', 'both'):
-            r = Q().givens_apply(a, cc, ss, 0, n - 1, side=side)
-            assert relerr(n_(r), g[k + f'givens_apply_{side}']) <= tol
-        assert relerr(n_(Q().givens_apply(a, cc, ss, 0, side='left')), g[k + 'givens_apply_default_j']) <= tol
-    h, us = Q().hessenberg(a, compute_u=True)
-    assert relerr(n_(h), g[k + 'hess']) <= tol
-    assert len(us) == max(n - 2, 0)
-    for i, ui in enumerate(us):
-        assert relerr(n_(ui), g[k + f'hess_u{i}']) <= tol
-    assert relerr(n_(Q().hessenberg(a)), g[k + 'hess']) <= tol
-    q, r = Q().qr_hessenberg(t(g[k + 'hz'], dev))
-    assert relerr(n_(q), g[k + 'qrh_q']) <= tol and relerr(n_(r), g[k + 'qrh_r']) <= tol
-    assert relerr(n_(Q().rq_hessenberg(t(g[k + 'hz'], dev))), g[k + 'rq_true']) <= tol
-    ev = np.sort(n_(Q().eig_sym(t(g[k + 'sym'], dev))), -1)
-    assert relerr(ev, g[k + 'eigvalsh']) <= 4 * tol
+def test_golden_family(dev, oracle, golden_qr, dn, n):
+    """the reference's own outputs: TOL for float64 and n <= 5, the error model of conftest
+    (truth = the float64 oracle on the same inputs) for float32 beyond"""
+    from test_oracle_golden import qr_family_cases
+    g, k = golden_qr, f'{dn}_n{n}_'
+    got = qr_family_cases(GpuQ(dev), g, k, n)
+    truth = qr_family_cases(oracle, g, k, n, f64=True) if dn == 'f32' else {}
+    for name, val in got.items():
+        assert parity_ok(val, g[k + name], n, dn, truth.get(name)), (name, relerr(val, g[k + name]))
+    assert not np.isnan(got['hh_u_b0']).any() and len([x for x in got if x.startswith('hess_u')]) == max(n - 2, 0)
+    assert parity_ok(n_(Q().hessenberg(t(g[k + 'a'], dev))), g[k + 'hess'], n, dn, truth.get('hess'))
+    # eigenvalues of the symmetrised matrix, both arithmetic modes: the golden vector is LAPACK in
+    # float64 = the truth of the model
+    for mode in ('reference', 'fast'):
+        ev = np.sort(GpuQ(dev, mode).eig_sym(g[k + 'sym']), -1)
+        assert within_model(ev, g[k + 'eigvalsh'], g[k + 'eigvalsh'], n, dn), (mode, relerr(ev, g[k + 'eigvalsh']))
 
 
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 @pytest.mark.parametrize('n', [1, 2, 3, 4, 5])
 def test_golden_sym_family(dev, golden_qr, dn, n):
-    g, k, tol = golden_qr, f'{dn}_n{n}_', qr_tol(dn, n)
-    a, sym = t(g[k + 'a'], dev), t(g[k + 'sym'], dev)
+    """orders where the reference itself runs: TOL (1e-6 / 1e-12), no scaling.  The reference-order
+    arithmetic reproduces the deflation ORDER and the eigenvector SIGNS of the reference."""
+    g, k, tol = golden_qr, f'{dn}_n{n}_', TOL[dn]
+    G = GpuQ(dev, 'reference')
+    a, sym = g[k + 'a'], g[k + 'sym']
     for up in (1, 0):
-        tt, us = Q().hessenberg_sym(sym, upper=bool(up), compute_u=True)
-        assert relerr(n_(tt), g[k + f'hess_sym_{up}']) <= tol
+        tt, us = G.hessenberg_sym(sym, upper=bool(up), compute_u=True)
+        assert relerr(tt, g[k + f'hess_sym_{up}']) <= tol
         for i, ui in enumerate(us):
-            assert relerr(n_(ui), g[k + f'hess_sym_{up}_u{i}']) <= tol
-        assert relerr(n_(Q().hessenberg_sym(a, upper=bool(up))), g[k + f'hess_nonsym_{up}']) <= tol
-        assert relerr(n_(Q().eig_sym(a, upper=bool(up))), g[k + f'eig_{up}']) <= 4 * tol
-    assert relerr(n_(Q().eig_sym(sym)), g[k + 'eig']) <= 4 * tol        # same deflation ORDER
-    ev, evec = Q().eig_sym(sym, compute_u=True)
-    assert relerr(n_(ev), g[k + 'eig_u_val']) <= 4 * tol and relerr(n_(evec), g[k + 'eig_u_vec']) <= 8 * tol
-    assert relerr(np.sort(n_(ev), -1), np.sort(g[k + 'eig_batched'], -1)) <= 4 * tol
-    assert relerr(n_(Q().rq_hessenberg(t(g[k + 'tri'], dev))), g[k + 'rq_tri']) <= tol
-    eye = torch.eye(n, dtype=a.dtype, device=dev).expand(a.shape)
-    h2, u2 = Q().rq_hessenberg(t(g[k + 'tri'], dev), eye)
-    assert relerr(n_(u2), g[k + 'rq_tri_u']) <= tol and relerr(n_(h2), g[k + 'rq_tri']) <= tol
+            assert relerr(ui, g[k + f'hess_sym_{up}_u{i}']) <= tol
+        assert relerr(G.hessenberg_sym(a, upper=bool(up)), g[k + f'hess_nonsym_{up}']) <= tol
+        assert relerr(G.eig_sym(a, upper=bool(up)), g[k + f'eig_{up}']) <= tol
+    assert relerr(G.eig_sym(sym), g[k + 'eig']) <= tol        # same deflation ORDER
+    ev, evec = G.eig_sym(sym, compute_u=True)
+    assert relerr(ev, g[k + 'eig_u_val']) <= tol and relerr(evec, g[k + 'eig_u_vec']) <= 2 * tol
+    assert relerr(np.sort(ev, -1), np.sort(g[k + 'eig_batched'], -1)) <= tol
+    assert relerr(G.rq_hessenberg(g[k + 'tri']), g[k + 'rq_tri']) <= tol
+    eye = np.broadcast_to(np.eye(n, dtype=a.dtype), a.shape).copy()
+    h2, u2 = G.rq_hessenberg(g[k + 'tri'], eye)
+    assert relerr(u2, g[k + 'rq_tri_u']) <= tol and relerr(h2, g[k + 'rq_tri']) <= tol
+    # the fast float32 sweeps: the same eigenvalues as a SET within the error model (order and signs
+    # are not specified upstream, `qr.py:45-46`), eigenpairs checked by their defining equations
+    F = GpuQ(dev, 'fast')
+    truth = np.linalg.eigvalsh(sym.astype(np.float64))
+    ev, evec = F.eig_sym(sym, compute_u=True)
+    assert within_model(np.sort(ev, -1), np.sort(g[k + 'eig'], -1), truth, n, dn)
+    check_eigenpairs(sym, ev, evec, n, dn)
+
+
+def check_eigenpairs(sym, ev, evec, n, dn):
+    """A U = U diag(s) and U^T U = I to c n eps (scaled by |A|)"""
+    s64, ev, evec = sym.astype(np.float64), ev.astype(np.float64), evec.astype(np.float64)
+    scale = max(np.abs(s64).max(), 1.0)
+    res = np.einsum('bij,bjk->bik', s64, evec) - evec * ev[:, None, :]
+    assert np.abs(res).max() <= 16 * n * EPS[dn] * scale, np.abs(res).max()
+    gram = np.einsum('bji,bjk->bik', evec, evec)
+    assert np.abs(gram - np.eye(n)).max() <= 16 * n * EPS[dn]
 
 
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 @pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16])
 def test_vs_oracle(dev, oracle, dn, n):
-    """seeded inputs, every order (orders > 5 raise upstream), ragged batch"""
+    """seeded inputs, every order (orders > 5 raise upstream), ragged batch.  The kernels run the
+    oracle's operation order, so everything except the fast float32 sweeps is held to TOL against
+    the oracle at EVERY order (measured: bit-identical)."""
     dtype = np.float32 if dn == 'f32' else np.float64
-    tol = qr_tol(dn, n)
+    tol = TOL[dn]
     nb = 777 if n <= 8 else 130
     rng = np.random.default_rng(1000 + n)
     a = rng.standard_normal((nb, n, n)).astype(dtype)
     sym = ((a + a.transpose(0, 2, 1)) / 2).astype(dtype)
     ad, sd = t(a, dev), t(sym, dev)
-    ev = n_(Q().eig_sym(sd))
     ref = oracle.eig_sym(sym)
-    # identical algorithm, identical operation order: same deflation order; tolerance
-    # covers the few matrices where one extra iteration is taken
-    assert relerr(np.sort(ev, -1), np.sort(ref, -1)) <= 4 * tol
-    assert relerr(np.sort(ev, -1), np.linalg.eigvalsh(sym.astype(np.float64))) <= 8 * tol
-    frac_same_order = np.mean(np.abs(ev - ref).max(-1) <= 8 * tol * max(np.abs(ref).max(), 1))
-    assert frac_same_order >= 0.98, frac_same_order
-    ev2, evec = Q().eig_sym(sd, compute_u=True)
-    ev2, evec = n_(ev2).astype(np.float64), n_(evec).astype(np.float64)
-    s64 = sym.astype(np.float64)
-    # A U = U diag(s), U orthonormal
-    res = np.einsum('bij,bjk->bik', s64, evec) - evec * ev2[:, None, :]
-    assert np.abs(res).max() <= 40 * tol * max(np.abs(s64).max(), 1)
-    gram = np.einsum('bji,bjk->bik', evec, evec)
-    assert np.abs(gram - np.eye(n)).max() <= 40 * tol
+    truth = np.linalg.eigvalsh(sym.astype(np.float64))
+    # reference-order arithmetic: the oracle's values in the oracle's order
+    ev = n_(Q().eig_sym(sd, arithmetic='reference'))
+    assert relerr(ev, ref) <= tol
+    # fast float32 sweeps (float64: the same kernel as above): the same set within the error model
+    evf = n_(Q().eig_sym(sd, arithmetic='fast'))
+    assert within_model(np.sort(evf, -1), np.sort(ref, -1), truth, n, dn), relerr(np.sort(evf, -1), truth)
+    if dn == 'f64':
+        assert np.array_equal(evf, ev)
+    for mode in ('reference', 'fast'):
+        ev2, evec = Q().eig_sym(sd, compute_u=True, arithmetic=mode)
+        check_eigenpairs(sym, n_(ev2), n_(evec), n, dn)
+        assert within_model(np.sort(n_(ev2), -1), np.sort(ref, -1), truth, n, dn)
     for up in (True, False):
         assert relerr(n_(Q().hessenberg_sym(ad, upper=up)), oracle.hessenberg_sym(a, up, True)) <= tol
     h, us = Q().hessenberg(ad, compute_u=True)
@@ -137,10 +185,11 @@ def test_vs_oracle(dev, oracle, dn, n):
     q, r = Q().qr_hessenberg(t(hz, dev))
     qo, ro = oracle.qr_hessenberg(hz)
     assert relerr(n_(q), qo) <= tol and relerr(n_(r), ro) <= tol
-    assert np.abs(np.einsum('bij,bjk->bik', n_(q).astype(np.float64), n_(r).astype(np.float64)) - hz).max() <= 20 * tol * 4
+    assert np.abs(np.einsum('bij,bjk->bik', n_(q).astype(np.float64), n_(r).astype(np.float64)) - hz).max() \
+        <= 16 * n * EPS[dn] * np.abs(hz).max()
     rq = n_(Q().rq_hessenberg(t(hz, dev)))
     assert relerr(rq, oracle.rq_hessenberg(hz)) <= tol
-    assert relerr(rq, np.einsum('bij,bjk->bik', ro.astype(np.float64), qo.astype(np.float64))) <= 4 * tol
+    assert relerr(rq, np.einsum('bij,bjk->bik', ro.astype(np.float64), qo.astype(np.float64))) <= 4 * n * EPS[dn] + tol
     v = rng.standard_normal((nb, n)).astype(dtype)
     for b in (0, n - 1):
         u, al = Q().householder(t(v, dev), basis=b, return_alpha=True)
@@ -150,7 +199,7 @@ def test_vs_oracle(dev, oracle, dn, n):
         px = v.astype(np.float64) - 2 * uo.astype(np.float64) * (uo.astype(np.float64) * v).sum(-1, keepdims=True)
         e = np.zeros((nb, n)); e[:, b] = alo
         if n > 1:
-            assert np.abs(px - e).max() <= 20 * tol * np.abs(v).max()
+            assert np.abs(px - e).max() <= 16 * n * EPS[dn] * np.abs(v).max()
 
 
 def test_layouts_and_errors(dev, oracle):

@@ -129,12 +129,9 @@ def test_reduce_empty(oracle, golden_reduce):
 
 
 # ------------------------------------------------------------------ QR family
-# The reference's own fp32 results drift from the fp64 truth as the order grows (its
-# Householder reductions are ~9e-6 off at n = 12); the tolerance scales accordingly.
-def qr_tol(dn, n):
-    return TOL[dn] * max(1.0, n * n / 4.0)
-
-
+# f64 and orders <= 5 (where the reference itself runs): TOL against the golden vectors.
+# float32 beyond: the error model of conftest (`parity_ok`), the truth being the float64 oracle
+# on the same inputs -- the reference's own fp32 Householder reduction is 9e-6 off at n = 12.
 QR_NS = (1, 2, 3, 4, 5, 6, 8, 12)
 
 
@@ -153,46 +150,59 @@ def test_qr_givens(oracle, golden_qr, dn):
     assert c[0] == 1 and s[0] == 0          # x = y = 0 -> identity rotation
 
 
+def qr_family_cases(O, g, k, n, f64=False):
+    """every (name, value) the QR-family goldens of order n hold, computed by backend `O` from the
+    golden inputs (cast to float64 when f64: that run is the truth of the error model)"""
+    up = (lambda x: x.astype(np.float64)) if f64 else (lambda x: x)
+    a, v, hz = up(g[k + 'a']), up(g[k + 'hh_x']), up(g[k + 'hz'])
+    out = {}
+    for b in sorted({0, n - 1}):
+        u, al = O.householder(v, b)
+        out[f'hh_u_b{b}'], out[f'hh_alpha_b{b}'] = u, al
+    # the reflector fed to the apply cases is the golden one, so that only the apply is compared
+    u = up(g[k + 'hh_u_b0'])
+    for side in ('left', 'right', 'both'):
+        out[f'hh_apply_{side}'] = O.householder_apply(a, u, side)
+    if n >= 3:
+        u2, _ = O.householder(up(g[k + 'hh_x'])[:, 1:])
+        out['hh_apply_short'] = O.householder_apply(a, u2, 'both')
+        out['hh_apply_two_inv'] = O.householder_apply(a, [u, u2], 'left', True)
+    if n >= 2:
+        cc, ss = up(g[k + 'ga_c'])[:, None], up(g[k + 'ga_s'])[:, None]
+        for side in ('left', 'right', 'both'):
+            out[f'givens_apply_{side}'] = O.givens_apply(a, cc, ss, 0, n - 1, side)
+        out['givens_apply_default_j'] = O.givens_apply(a, cc, ss, 0, None, 'left')
+    h, us = O.hessenberg(a, True)
+    out['hess'] = h
+    for i, ui in enumerate(us):
+        out[f'hess_u{i}'] = ui
+    out['qrh_q'], out['qrh_r'] = O.qr_hessenberg(hz)
+    out['rq_true'] = O.rq_hessenberg(hz)
+    return out
+
+
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 @pytest.mark.parametrize('n', QR_NS)
 def test_qr_family(oracle, golden_qr, dn, n):
-    g, k, tol = golden_qr, f'{dn}_n{n}_', qr_tol(dn, n)
-    a, v = g[k + 'a'], g[k + 'hh_x']
-    for b in sorted({0, n - 1}):
-        u, al = oracle.householder(v, b)
-        assert relerr(u, g[k + f'hh_u_b{b}']) <= tol and relerr(al, g[k + f'hh_alpha_b{b}']) <= tol
-        assert not np.isnan(u).any()
-    u, _ = oracle.householder(v)
-    for side in ('left', 'right', 'both'):
-        assert relerr(oracle.householder_apply(a, u, side), g[k + f'hh_apply_{side}']) <= tol
-    if n >= 3:
-        u2, _ = oracle.householder(v[:, 1:])
-        assert relerr(oracle.householder_apply(a, u2, 'both'), g[k + 'hh_apply_short']) <= tol
-        assert relerr(oracle.householder_apply(a, [u, u2], 'left', True), g[k + 'hh_apply_two_inv']) <= tol
-    if n >= 2:
-        cc, ss = g[k + 'ga_c'][:, None], g[k + 'ga_s'][:, None]
-        for side in ('left', 'right', 'both'):
-            assert relerr(oracle.givens_apply(a, cc, ss, 0, n - 1, side), g[k + f'givens_apply_{side}']) <= tol
-        assert relerr(oracle.givens_apply(a, cc, ss, 0, None, 'left'), g[k + 'givens_apply_default_j']) <= tol
-    h, us = oracle.hessenberg(a, True)
-    assert relerr(h, g[k + 'hess']) <= tol
-    for i, ui in enumerate(us):
-        assert relerr(ui, g[k + f'hess_u{i}']) <= tol
-    q, r = oracle.qr_hessenberg(g[k + 'hz'])
-    assert relerr(q, g[k + 'qrh_q']) <= tol and relerr(r, g[k + 'qrh_r']) <= tol
-    assert relerr(oracle.rq_hessenberg(g[k + 'hz']), g[k + 'rq_true']) <= tol
+    from conftest import parity_ok, within_model
+    g, k = golden_qr, f'{dn}_n{n}_'
+    got = qr_family_cases(oracle, g, k, n)
+    truth = qr_family_cases(oracle, g, k, n, f64=True) if dn == 'f32' else {}
+    for name, val in got.items():
+        assert parity_ok(val, g[k + name], n, dn, truth.get(name)), (name, relerr(val, g[k + name]))
+    assert not np.isnan(got['hh_u_b0']).any()
     if n <= 3:
-        assert relerr(oracle.rq_hessenberg(g[k + 'hz'], true_rq=False), g[k + 'rq_ref']) <= tol
-    # eigenvalues of the symmetrised matrix against LAPACK (sorted), any n
+        assert relerr(oracle.rq_hessenberg(g[k + 'hz'], true_rq=False), g[k + 'rq_ref']) <= TOL[dn]
+    # eigenvalues of the symmetrised matrix: the golden vector is LAPACK in float64 = the truth
     ev = np.sort(oracle.eig_sym(g[k + 'sym']), -1)
-    assert relerr(ev, g[k + 'eigvalsh']) <= 4 * tol
+    assert within_model(ev, g[k + 'eigvalsh'], g[k + 'eigvalsh'], n, dn), relerr(ev, g[k + 'eigvalsh'])
 
 
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 @pytest.mark.parametrize('n', [1, 2, 3, 4, 5])
 def test_qr_sym_family(oracle, golden_qr, dn, n):
-    """orders where the reference itself runs (quirk Q7)"""
-    g, k, tol = golden_qr, f'{dn}_n{n}_', qr_tol(dn, n)
+    """orders where the reference itself runs (quirk Q7): TOL, no scaling"""
+    g, k, tol = golden_qr, f'{dn}_n{n}_', TOL[dn]
     a, sym = g[k + 'a'], g[k + 'sym']
     for up in (1, 0):
         t, us = oracle.hessenberg_sym(sym, bool(up), True, True)
@@ -201,13 +211,13 @@ def test_qr_sym_family(oracle, golden_qr, dn, n):
             assert relerr(ui, g[k + f'hess_sym_{up}_u{i}']) <= tol
         # un-symmetrised input: only the requested triangle may be read
         assert relerr(oracle.hessenberg_sym(a, bool(up), True), g[k + f'hess_nonsym_{up}']) <= tol
-        assert relerr(oracle.eig_sym(a, upper=bool(up)), g[k + f'eig_{up}']) <= 4 * tol
+        assert relerr(oracle.eig_sym(a, upper=bool(up)), g[k + f'eig_{up}']) <= tol
     # same ORDER (deflation order) and same eigenvector signs as the reference on one matrix
-    assert relerr(oracle.eig_sym(sym), g[k + 'eig']) <= 4 * tol
+    assert relerr(oracle.eig_sym(sym), g[k + 'eig']) <= tol
     ev, evec = oracle.eig_sym(sym, True)
-    assert relerr(ev, g[k + 'eig_u_val']) <= 4 * tol and relerr(evec, g[k + 'eig_u_vec']) <= 8 * tol
+    assert relerr(ev, g[k + 'eig_u_val']) <= tol and relerr(evec, g[k + 'eig_u_vec']) <= 2 * tol
     # batched upstream call: same multiset (its order depends on the batch, quirk Q9)
-    assert relerr(np.sort(ev, -1), np.sort(g[k + 'eig_batched'], -1)) <= 4 * tol
+    assert relerr(np.sort(ev, -1), np.sort(g[k + 'eig_batched'], -1)) <= tol
     assert relerr(oracle.rq_hessenberg(g[k + 'tri']), g[k + 'rq_tri']) <= tol
     eye = np.broadcast_to(np.eye(n, dtype=a.dtype), a.shape)
     assert relerr(oracle.rq_hessenberg(g[k + 'tri'], eye)[1], g[k + 'rq_tri_u']) <= tol
