@@ -47,6 +47,8 @@ def batchdet(a):
     dev, dtype, (a,) = _prep(a)
     n = a.shape[-1]
     assert a.shape[-2] == n, 'Expected square matrices'
+    if n > _lib.MAX_DIM:          # the reference's own route for every order (`_impl/batched.py:53-54`), on the device
+        return torch.linalg.det(a)
     batch = a.shape[:-2]
     out = torch.empty(batch, dtype=dtype, device=dev)
     b = Batch(batch, [a, out], [2, 0], pack=n > 8)
@@ -74,6 +76,8 @@ def batchinv(a, perturb=False):
     dev, dtype, (a,) = _prep(a)
     n = a.shape[-1]
     assert a.shape[-2] == n, 'Expected square matrices'
+    if n > _lib.MAX_DIM:          # `a.inverse()` (`_impl/batched.py:119-120`), on the device
+        return torch.linalg.inv(a)
     batch = a.shape[:-2]
     out = _like_or_contiguous(a if n <= 8 else None, tuple(batch) + (n, n), dtype, dev)
     b = Batch(batch, [a, out], [2, 2], pack=n > 8)

@@ -396,9 +396,9 @@ inline bool tile_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_
 {
     if (op->ptr == nullptr) return false;
     // any element-aligned base: the tile's 16-byte global accesses only need dword alignment
-    // (VecOf::gtype); NFM_TILE_ALIGN16=1 restores the old 16-byte requirement (A/B measurements)
-    static const bool align16 = [] { const char *e = getenv("NFM_TILE_ALIGN16"); return e && e[0] == '1'; }();
-    if (reinterpret_cast<uintptr_t>(op->ptr) % (align16 ? 16 : elem) != 0) return false;
+    // (VecOf::gtype; measured: a base 4 bytes off a 16-byte line streams at the aligned rate,
+    // 5.85 vs 5.63 TB/s for the 4x4 solve, profiles/r02/layouts_table.md)
+    if (reinterpret_cast<uintptr_t>(op->ptr) % elem != 0) return false;
     if (n_outer != 1) return false; // the facade collapses contiguous outer levels into one
     if (op->stride_inner != C) return false;
     if (rows > 1) {
@@ -410,13 +410,11 @@ inline bool tile_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_
 }
 
 // Can the operand be moved with one packed 4/8/16-byte access per lane?  Records back
-// to back along the inner batch level, every record (and every outer slab) aligned to
-// the record size.
+// to back along the inner batch level, outer slabs a whole number of records apart.
 inline bool vec_ok(const nfm_operand *op, int C, int rows, int cols, int64_t n_outer, size_t elem)
 {
     if (op->ptr == nullptr) return false;
-    const size_t rb = (size_t)C * elem;
-    if (reinterpret_cast<uintptr_t>(op->ptr) % rb != 0) return false;
+    if (reinterpret_cast<uintptr_t>(op->ptr) % elem != 0) return false; // PackOf is element-aligned
     if (op->stride_inner != C) return false;
     if (n_outer > 1 && (op->stride_outer % C) != 0) return false;
     if (rows > 1) {

@@ -5,6 +5,7 @@
 #include "nfm_sym_ops.hpp"
 #include "nfm_batched_ops.hpp"
 #include "nfm_large.hpp"
+#include "nfm_rowwave.hpp"
 
 #ifndef NFM_LARGE_PART
 #error "compile with -DNFM_LARGE_PART=0..31"
@@ -39,7 +40,9 @@ namespace nfm {
     switch (Nexpr) { NFM_LCASE(15, __VA_ARGS__) NFM_LCASE(16, __VA_ARGS__) default: break; }
 #endif
 
-// Every op covers orders 9..16 in both dtypes.  The pivoting code uses OPAQUE selects here
+// Every op covers the orders 9..16 of both dtypes that rowwave_choice (nfm_rowwave.hpp) leaves
+// to the lane-per-matrix form; the others (the ones that did not fit the register file) answer
+// NFM_EFALLBACK without instantiating a kernel.  The pivoting code uses OPAQUE selects here
 // (Sel<true>, nfm_smallmat.hpp): no data-dependent control flow is left, so whatever spill
 // code the big eliminations need runs under a full EXEC mask, and most kernels need none
 // (-Rpass-analysis=kernel-resource-usage: every f32 kernel and f64 up to 13 are spill-free).
@@ -56,6 +59,8 @@ using TL = double;
 #define NFM_LNAME(op) NFM_LNAME2(op, f64, NFM_LQ)
 #endif
 #define NFM_LNAME2(op, t, h) NFM_LNAME3(op, t, h)
+// does the lane-per-matrix form keep (dtype TL, order N, op `what`)?
+#define NFM_LKEEP(N, what) (rowwave_choice(sizeof(TL) == 8, N, what).rows == 0)
 #define NFM_LNAME3(op, t, h) large_##op##_##t##_q##h
 
 #if NFM_LGROUP == 0
@@ -65,13 +70,15 @@ int NFM_LNAME(sym_solve)(int M, int64_t ni, const nfm_operand *mat, const nfm_op
     SolveParams p;
     p.has_eps = eps != nullptr;
     for (int i = 0; i < NFM_MAX_DIM; ++i) p.eps[i] = (eps && i < M) ? eps[i] : 0.0;
-    NFM_LSWITCH16(M, return (rec_launch<TL, SolveOp<TL, N, NFM_MAT_SYM>, true>(mat, vec, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(M, if constexpr (NFM_LKEEP(N, RWW_SOLVE))
+                     return (rec_launch<TL, SolveOp<TL, N, NFM_MAT_SYM>, true>(mat, vec, nullptr, out, 1, ni, p, stream)))
     return NFM_EFALLBACK;
 }
 int NFM_LNAME(sym_det)(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream)
 {
     NoParams p{0};
-    NFM_LSWITCH16(M, return (rec_launch<TL, DetOp<TL, N>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(M, if constexpr (NFM_LKEEP(N, RWW_DET_SYM))
+                     return (rec_launch<TL, DetOp<TL, N>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
     return NFM_EFALLBACK;
 }
 #endif
@@ -80,7 +87,8 @@ int NFM_LNAME(sym_det)(int M, int64_t ni, const nfm_operand *mat, const nfm_oper
 int NFM_LNAME(sym_invert)(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream)
 {
     InvParams p{0};
-    NFM_LSWITCH16(M, return (rec_launch<TL, InvStreamOp<TL, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(M, if constexpr (NFM_LKEEP(N, RWW_INV_SYM))
+                     return (rec_launch<TL, InvStreamOp<TL, N, true>, true>(mat, nullptr, nullptr, out, 1, ni, p, stream)))
     return NFM_EFALLBACK;
 }
 #endif
@@ -89,7 +97,8 @@ int NFM_LNAME(sym_invert)(int M, int64_t ni, const nfm_operand *mat, const nfm_o
 int NFM_LNAME(batch_inv)(int N_, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
     InvParams p{0};
-    NFM_LSWITCH16(N_, return (rec_launch<TL, InvStreamOp<TL, N, false>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(N_, if constexpr (NFM_LKEEP(N, RWW_INV_GEN))
+                      return (rec_launch<TL, InvStreamOp<TL, N, false>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
     return NFM_EFALLBACK;
 }
 #endif
@@ -105,7 +114,8 @@ int NFM_LNAME(sym_matvec)(int M, int mode, int64_t ni, const nfm_operand *mat, c
 int NFM_LNAME(batch_det)(int N_, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
     NoParamsB p{0};
-    NFM_LSWITCH16(N_, return (rec_launch<TL, BatchDetOp<TL, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
+    NFM_LSWITCH16(N_, if constexpr (NFM_LKEEP(N, RWW_DET_GEN))
+                      return (rec_launch<TL, BatchDetOp<TL, N>, true>(a, nullptr, nullptr, out, 1, ni, p, stream)))
     return NFM_EFALLBACK;
 }
 #endif

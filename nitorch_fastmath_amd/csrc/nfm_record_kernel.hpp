@@ -57,9 +57,11 @@ struct RecIO {
     static constexpr int pref_soa = can_soa ? MODE_SOA : (R::used && R::C == 1 ? MODE_VEC : MODE_STRIDED);
 };
 
+// element-aligned on purpose: a packed 8 / 16-byte global access only needs dword alignment on
+// gfx950 (same instruction), so records at any element offset keep the one-access-per-lane path
 template <typename T, int C>
 struct PackOf {
-    typedef T type __attribute__((ext_vector_type(C)));
+    typedef T type __attribute__((ext_vector_type(C), aligned(sizeof(T))));
 };
 template <typename T>
 struct PackOf<T, 1> {
@@ -394,27 +396,6 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
         return m;
     };
     Modes md = classify(a, b, c, out, n_inner);
-    if constexpr (!FAST_ONLY) {
-        // Contiguous batch-major operands whose base is not 16-byte aligned (an odd row offset
-        // of a sliced tensor): peel the first r records off into a tiny run-time-mode launch if
-        // the rest of the batch then starts aligned for EVERY operand.
-        if (!md.fast && n_outer == 1) {
-            const int V = 16 / (int)sizeof(T);
-            for (int r = 1; r < V && r < n_inner; ++r) {
-                auto shifted = [&](const nfm_operand *op) {
-                    nfm_operand s = *op;
-                    if (s.ptr) s.ptr = static_cast<char *>(s.ptr) + (int64_t)r * s.stride_inner * (int64_t)sizeof(T);
-                    return s;
-                };
-                const nfm_operand sa = shifted(a), sb = shifted(b), sc = shifted(c), so = shifted(out);
-                if (classify(&sa, &sb, &sc, &so, n_inner - r).fast) {
-                    const int rc = rec_launch<T, Op, false>(a, b, c, out, 1, r, prm, stream);
-                    if (rc != NFM_OK) return rc;
-                    return rec_launch<T, Op, false>(&sa, &sb, &sc, &so, 1, n_inner - r, prm, stream);
-                }
-            }
-        }
-    }
     const int ma = md.ma, mb = md.mb, mc = md.mc, mo = md.mo;
     const bool any = md.any, fast = md.fast;
     constexpr int TILE_F = KindTile<T, Op, KIND_AOS>::value; // lanes per workgroup of the AoS variant

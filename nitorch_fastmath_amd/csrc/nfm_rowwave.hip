@@ -78,15 +78,6 @@ __device__ __forceinline__ unsigned rowmax_step(unsigned v)
     const unsigned o = (unsigned)dpp_ror<ROR>((int)v);
     return v > o ? v : o;
 }
-// max over the 16 lanes of a DPP row, in every lane of the row
-__device__ __forceinline__ unsigned rowmax(unsigned v)
-{
-    v = rowmax_step<8>(v);
-    v = rowmax_step<4>(v);
-    v = rowmax_step<2>(v);
-    return rowmax_step<1>(v);
-}
-
 __device__ __forceinline__ float recip(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);
@@ -117,26 +108,68 @@ __device__ __forceinline__ int cidx(int N, int i, int j)
     return i == j ? i : N + lo * N - (lo * (lo + 1)) / 2 + (hi - lo - 1);
 }
 
+// elements of the LDS image of a tile of MPB matrices (input records, reused for the output)
 template <typename T, int N, int OP>
-__global__ __launch_bounds__(256) void roww_kernel(const T *__restrict__ A, const T *__restrict__ B,
-                                                   T *__restrict__ O, int64_t n, RowParams p)
+__host__ __device__ constexpr int img_elems()
+{
+    constexpr bool SYM = OP == RW_SOLVE_SYM || OP == RW_INV_SYM || OP == RW_INVDIAG_SYM || OP == RW_DET_SYM;
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int raw = SYM ? MPB * (N * (N + 1) / 2) : MPB * N * RowStride<T, N>::value;
+    return ((raw + V - 1) / V) * V;
+}
+
+// max over the G = 16 / R lanes of a matrix, in every one of them
+template <int G>
+__device__ __forceinline__ unsigned groupmax(unsigned v)
+{
+    if constexpr (G == 16) {
+        v = rowmax_step<8>(v);
+        v = rowmax_step<4>(v);
+        v = rowmax_step<2>(v);
+        return rowmax_step<1>(v);
+    } else {
+        auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+        v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false)); // quad_perm [1,0,3,2]
+        v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false)); // quad_perm [2,3,0,1]
+        if constexpr (G == 8) v = mx(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false)); // row_half_mirror
+        return v;
+    }
+}
+
+// R rows per lane, G = 16 / R lanes per matrix, 16 matrices per workgroup of 16 * G lanes.
+// The pivot row is broadcast once per wavefront whatever R is (ds_bpermute runs at one
+// wave-instruction per ~6.5 clocks per CU and is what bounds the R = 1 form), so R = 2 / 4
+// spread that cost over 2x / 4x the matrices, for R x the fma work and registers per lane.
+//
+// LB: how the pivot row reaches the other lanes.  false: ds_bpermute, one per dword.  true: the
+// pivot lane writes the row into a per-matrix LDS slot (ds_write_b128, one lane per matrix active)
+// and every lane reads it back (ds_read_b128 of one address per matrix: a broadcast read, 16 bytes
+// per lane per instruction) -- LDS operations of a wavefront execute in order, so no barrier.
+template <typename T, int N, int OP, int R, bool LB>
+__global__ __launch_bounds__(256 / R) void roww_kernel(const T *__restrict__ A, const T *__restrict__ B,
+                                                       T *__restrict__ O, int64_t n, RowParams p)
 {
     constexpr bool SYM = OP == RW_SOLVE_SYM || OP == RW_INV_SYM || OP == RW_INVDIAG_SYM || OP == RW_DET_SYM;
     constexpr bool INV = OP == RW_INV_SYM || OP == RW_INVDIAG_SYM || OP == RW_INV_GEN;
     constexpr bool DET = OP == RW_DET_SYM || OP == RW_DET_GEN;
+    constexpr int G = 16 / R;             // lanes per matrix
+    constexpr int NT = MPB * G;           // lanes per workgroup
     constexpr int K = N * (N + 1) / 2;
     constexpr int RIN = SYM ? K : N * N;                                    // input record
     constexpr int ROUT = OP == RW_SOLVE_SYM ? N : OP == RW_INV_SYM ? K : OP == RW_INVDIAG_SYM ? N : DET ? 1 : N * N;
     constexpr int V = 16 / (int)sizeof(T);
     constexpr int RS = RowStride<T, N>::value;
     using Vec = T __attribute__((ext_vector_type(V)));
+    constexpr int NS = ((N + 1 + V - 1) / V) * V; // pivot-row slot of a matrix: N values + the right-hand side
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T *img = reinterpret_cast<T *>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int g = tid / G, r = tid % G;
-    const int gbase = lane & 48; // first lane of this matrix's DPP row within the wavefront
+    const int g = tid / G, lr = tid % G;  // matrix of the tile, lane within the matrix
+    T *slot = img + img_elems<T, N, OP>() + g * NS; // LB: this matrix's pivot-row slot
+    const int gbase = lane & ~(G - 1);    // first lane of this matrix within the wavefront
+    const unsigned gmask = (1u << G) - 1u;
     const int64_t m0 = (int64_t)blockIdx.x * MPB;
     const int nm = (int)((n - m0) < MPB ? (n - m0) : MPB);
 
@@ -147,7 +180,7 @@ __global__ __launch_bounds__(256) void roww_kernel(const T *__restrict__ A, cons
         // a tile starts a whole number of 16-matrix blocks into the operand: 16-byte aligned exactly
         // when the operand's base is (row slices x[i:] of float64 tensors may not be)
         const bool vec_ok = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-        for (int e = tid * V; e < total; e += 256 * V) {
+        for (int e = tid * V; e < total; e += NT * V) {
             if (vec_ok && e + V <= total) {
                 const Vec v = NFM_LDG(reinterpret_cast<const Vec *>(src + e));
                 if constexpr (SYM) { // flat copy of the compact records
@@ -173,60 +206,106 @@ __global__ __launch_bounds__(256) void roww_kernel(const T *__restrict__ A, cons
     }
     __syncthreads();
 
-    // ---- my row
-    const bool live = r < N && g < nm;
-    T row[N];
-    if constexpr (SYM) {
+    // ---- my rows: row id of slot t is lr + t * G
+    T row[R][N];
+    T rhs[R];
+    bool used[R];
+    int ppos[R];   // the step at which the row pivoted = the row of the result it ends up holding
+    T mypv[R];     // inverse: the pivot of the row (rows are scaled once, at the end)
 #pragma unroll
-        for (int j = 0; j < N; ++j) row[j] = live ? img[g * K + cidx(N, r, j)] : T(0);
-        if (OP == RW_SOLVE_SYM && p.has_eps) {
+    for (int t = 0; t < R; ++t) {
+        const int rid = lr + t * G;
+        const bool live = rid < N && g < nm;
+        if constexpr (SYM) {
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (r == j) row[j] += (T)p.eps[j];
+            for (int j = 0; j < N; ++j) row[t][j] = live ? img[g * K + cidx(N, rid, j)] : T(0);
+            if (OP == RW_SOLVE_SYM && p.has_eps) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (rid == j) row[t][j] += (T)p.eps[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) row[t][j] = live ? img[(g * N + rid) * RS + j] : T(0);
         }
-    } else {
+        rhs[t] = T(0);
+        if constexpr (OP == RW_SOLVE_SYM) rhs[t] = live ? NFM_LDG(B + (m0 + g) * N + rid) : T(0);
+        used[t] = !(rid < N); // rows beyond the order never pivot
+        if (!(g < nm)) {      // idle matrices of a ragged last tile: the identity (nothing divides by zero)
 #pragma unroll
-        for (int j = 0; j < N; ++j) row[j] = live ? img[(g * N + r) * RS + j] : T(0);
+            for (int j = 0; j < N; ++j) row[t][j] = (rid == j) ? T(1) : T(0);
+        }
+        ppos[t] = -1;
+        mypv[t] = T(1);
     }
-    T rhs = T(0);
-    if constexpr (OP == RW_SOLVE_SYM) rhs = live ? NFM_LDG(B + (m0 + g) * N + r) : T(0);
-    // rows beyond the order (and matrices beyond the batch) never pivot
-    bool used = !(r < N);
-    if (!(g < nm)) { // idle matrices of a ragged last tile: the identity, so that nothing divides by zero
-#pragma unroll
-        for (int j = 0; j < N; ++j) row[j] = (r == j) ? T(1) : T(0);
-    }
-    int ppos = -1;   // the step at which my row was the pivot row = the logical row it holds
-    int src_of = 0;  // lane (within the DPP row) that pivoted at step r: where output row r lives
-    int pl_of[INV ? N : 1]; // inverse: pivot lane of every step (the column permutation)
+    int col_of[INV ? N : 1]; // inverse: row id of the pivot of every step (the column permutation)
     T det = T(1);
     int inversions = 0;
 
-    T mypv = T(1); // inverse: the pivot of my row (rows are scaled once, at the end)
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        // -- pivot: first unused row with the largest |a_rk| (pivot_key above)
-        const unsigned key = used ? 0u : pivot_key(row[k]);
-        const unsigned mx = rowmax(key);
-        const unsigned grp = (unsigned)(__ballot(key == mx) >> gbase) & 0xffffu; // never 0: some row is unused
-        const int pl = __builtin_ctz(grp | 0x10000u);
-        const bool isp = r == pl;
-        if (r == k) src_of = pl;
-        if constexpr (INV) pl_of[k] = pl;
-        if constexpr (DET) { // parity of the row permutation: unused rows above the pivot row
-            const unsigned un = (unsigned)(__ballot(!used) >> gbase) & 0xffffu;
-            inversions += __builtin_popcount(un & ((1u << pl) - 1u));
+        // -- pivot: first unused row with the largest |a_rk| (pivot_key above); slot first, then lane
+        unsigned key = 0;
+        int ts = 0; // my best slot
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const unsigned kt = used[t] ? 0u : pivot_key(row[t][k]);
+            ts = kt > key ? t : ts;
+            key = kt > key ? kt : key;
         }
+        const unsigned mx = groupmax<G>(key);
+        const unsigned grp = (unsigned)(__ballot(key == mx) >> gbase) & gmask; // never 0: some row is unused
+        const int pl = __builtin_ctz(grp | (1u << G));
+        const bool isl = lr == pl;      // my lane holds the pivot row, in slot ts
         const int psrc = gbase + pl;
-        const T pv = bcast(row[k], psrc);
-        // multiplier of my row; 0 in the pivot row itself, so that the same fma leaves it unchanged
-        // (a determinant with a zero pivot is 0 whatever follows: no elimination then)
-        T f = row[k] * pivot_recip(pv);
-        f = isp ? T(0) : f;
-        if constexpr (DET) {
-            det *= pv;
-            f = (pv == T(0)) ? T(0) : f;
+        int prid = 0;                   // row id of the pivot row
+        if constexpr (INV || DET) {
+            prid = R == 1 ? pl : bperm(psrc, lr + ts * G);
+            if constexpr (INV) col_of[k] = prid;
         }
+        if constexpr (DET) { // parity of the row permutation: unused rows with a smaller row id
+            unsigned un = 0;
+#pragma unroll
+            for (int t = 0; t < R; ++t) un |= ((unsigned)(__ballot(!used[t]) >> gbase) & gmask) << (t * G);
+            inversions += __builtin_popcount(un & ((1u << prid) - 1u));
+        }
+        // the pivot row of my lane's candidate slot (only the pivot lane's values are consumed)
+        T cand[N];
+        T crhs = rhs[0];
+#pragma unroll
+        for (int j = 0; j < N; ++j) cand[j] = row[0][j];
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) cand[j] = (ts == t) ? row[t][j] : cand[j];
+            crhs = (ts == t) ? rhs[t] : crhs;
+        }
+        if constexpr (LB) {
+            if (isl) { // INV needs the whole row, the others columns k.. and the right-hand side
+#pragma unroll
+                for (int j = INV ? 0 : k; j < N; ++j) slot[j] = cand[j];
+                if constexpr (OP == RW_SOLVE_SYM) slot[N] = crhs;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        auto pivot_row = [&](const T &mine, int j) -> T {
+            if constexpr (LB) return slot[j];
+            else return bcast(mine, psrc);
+        };
+        const T pv = pivot_row(cand[k], k);
+        const T rp = pivot_recip(pv);
+        // multipliers of my rows; 0 in the pivot row itself, so that the same fma leaves it unchanged
+        // (a determinant with a zero pivot is 0 whatever follows: no elimination then)
+        T f[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            f[t] = row[t][k] * rp;
+            f[t] = (isl && ts == t) ? T(0) : f[t];
+            if constexpr (DET) f[t] = (pv == T(0)) ? T(0) : f[t];
+        }
+        if constexpr (DET) det *= pv;
         if constexpr (INV) {
             // in-place Gauss-Jordan on [A | I] WITHOUT scaling the pivot row (rows are divided by their
             // pivots at the end): column k of A is spent, its slot takes the column of the right half
@@ -234,61 +313,80 @@ __global__ __launch_bounds__(256) void roww_kernel(const T *__restrict__ A, cons
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if (j == k) continue;
-                row[j] = fma_(-f, bcast(row[j], psrc), row[j]);
+                const T pj = pivot_row(cand[j], j);
+#pragma unroll
+                for (int t = 0; t < R; ++t) row[t][j] = fma_(-f[t], pj, row[t][j]);
             }
-            row[k] = isp ? T(1) : -f;
-            mypv = isp ? pv : mypv;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const bool me = isl && ts == t;
+                row[t][k] = me ? T(1) : -f[t];
+                mypv[t] = me ? pv : mypv[t];
+            }
         } else {
             // Gauss-Jordan on [A | b] (solve) or plain elimination (det): columns k+1.. only
 #pragma unroll
-            for (int j = k + 1; j < N; ++j) row[j] = fma_(-f, bcast(row[j], psrc), row[j]);
-            if constexpr (OP == RW_SOLVE_SYM) rhs = fma_(-f, bcast(rhs, psrc), rhs);
-        }
-        if (isp) {
-            used = true;
-            ppos = k;
-        }
-    }
-    if constexpr (INV) {
-        const T rp = T(1) / mypv;
+            for (int j = k + 1; j < N; ++j) {
+                const T pj = pivot_row(cand[j], j);
 #pragma unroll
-        for (int j = 0; j < N; ++j) row[j] *= rp;
+                for (int t = 0; t < R; ++t) row[t][j] = fma_(-f[t], pj, row[t][j]);
+            }
+            if constexpr (OP == RW_SOLVE_SYM) {
+                const T pb = pivot_row(crhs, N);
+#pragma unroll
+                for (int t = 0; t < R; ++t) rhs[t] = fma_(-f[t], pb, rhs[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const bool me = isl && ts == t;
+            used[t] = used[t] || me;
+            ppos[t] = me ? k : ppos[t];
+        }
+        if constexpr (LB) { // the slot is rewritten by the next step only after every lane has read it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 
-    // ---- results
+    // ---- results: slot t holds row ppos[t] of the result
     if constexpr (OP == RW_SOLVE_SYM) {
-        // my row holds x_ppos = rhs / pivot (its pivot is still at column ppos); output row r lives in lane src_of
-        T piv = T(1);
 #pragma unroll
-        for (int j = 0; j < N; ++j) piv = (ppos == j) ? row[j] : piv;
-        const T x = rhs / piv;
-        const T xr = bcast(x, gbase + src_of);
-        if (live) NFM_STG(xr, O + (m0 + g) * N + r);
+        for (int t = 0; t < R; ++t) {
+            T piv = T(1); // the pivot is still at column ppos of the row
+#pragma unroll
+            for (int j = 0; j < N; ++j) piv = (ppos[t] == j) ? row[t][j] : piv;
+            if (g < nm && ppos[t] >= 0) NFM_STG(rhs[t] / piv, O + (m0 + g) * N + ppos[t]);
+        }
     } else if constexpr (DET) {
         const T d = (inversions & 1) ? -det : det;
-        if (r == 0 && g < nm) NFM_STG(d, O + (m0 + g));
+        if (lr == 0 && g < nm) NFM_STG(d, O + (m0 + g));
     } else {
-        // lane p_k holds row k = ppos of A^-1; its l-th value is column pl_of[l]
+        // its l-th value is column col_of[l]
         __syncthreads(); // everyone is done reading the input image
-        if (r < N && g < nm && ppos >= 0) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            if (!(g < nm && ppos[t] >= 0)) continue;
+            const T rp = T(1) / mypv[t];
+            const int pr = ppos[t];
             if constexpr (OP == RW_INV_GEN) {
 #pragma unroll
-                for (int l = 0; l < N; ++l) img[(g * N + ppos) * RS + pl_of[l]] = row[l];
+                for (int l = 0; l < N; ++l) img[(g * N + pr) * RS + col_of[l]] = row[t][l] * rp;
             } else if constexpr (OP == RW_INV_SYM) {
 #pragma unroll
                 for (int l = 0; l < N; ++l)
-                    if (pl_of[l] >= ppos) img[g * K + cidx(N, ppos, pl_of[l])] = row[l];
+                    if (col_of[l] >= pr) img[g * K + cidx(N, pr, col_of[l])] = row[t][l] * rp;
             } else { // diagonal only
 #pragma unroll
                 for (int l = 0; l < N; ++l)
-                    if (pl_of[l] == ppos) img[g * N + ppos] = row[l];
+                    if (col_of[l] == pr) img[g * N + pr] = row[t][l] * rp;
             }
         }
         __syncthreads();
         T *dst = O + m0 * ROUT;
         const int total = nm * ROUT;
         const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-        for (int e = tid * V; e < total; e += 256 * V) {
+        for (int e = tid * V; e < total; e += NT * V) {
             T tmp[V];
             if constexpr (OP == RW_INV_GEN) {
 #pragma unroll
@@ -325,20 +423,46 @@ static bool rec_contig(const nfm_operand *o, int64_t rec, int rows, int cols, si
     return true;
 }
 
-template <typename T, int N, int OP>
-static int launch(const void *a, const void *b, void *o, int64_t n, const RowParams &p, void *stream)
+template <typename T, int N, int OP, int R, bool LB>
+static int launch_r(const void *a, const void *b, void *o, int64_t n, const RowParams &p, void *stream)
 {
-    constexpr bool SYM = OP == RW_SOLVE_SYM || OP == RW_INV_SYM || OP == RW_INVDIAG_SYM || OP == RW_DET_SYM;
-    constexpr int K = N * (N + 1) / 2;
-    constexpr int RS = RowStride<T, N>::value;
-    constexpr size_t lds = (SYM ? (size_t)MPB * K + 16 : (size_t)MPB * N * RS) * sizeof(T);
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int NS = ((N + 1 + V - 1) / V) * V;
+    constexpr size_t lds = ((size_t)img_elems<T, N, OP>() + (LB ? MPB * NS : 0)) * sizeof(T);
     static_assert(lds <= 64 * 1024, "row-wave tile must fit the default dynamic LDS limit");
     if (n == 0) return NFM_OK;
     const int64_t nblk = (n + MPB - 1) / MPB;
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
-    hipLaunchKernelGGL((roww_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(256), lds, static_cast<hipStream_t>(stream),
-                       static_cast<const T *>(a), static_cast<const T *>(b), static_cast<T *>(o), n, p);
+    hipLaunchKernelGGL((roww_kernel<T, N, OP, R, LB>), dim3((unsigned)nblk), dim3(256 / R), lds,
+                       static_cast<hipStream_t>(stream), static_cast<const T *>(a), static_cast<const T *>(b),
+                       static_cast<T *>(o), n, p);
     return launch_status();
+}
+
+constexpr int rww_of(int op)
+{
+    return op == RW_SOLVE_SYM ? RWW_SOLVE : op == RW_INV_SYM ? RWW_INV_SYM : op == RW_INVDIAG_SYM ? RWW_INVDIAG_SYM
+           : op == RW_DET_SYM ? RWW_DET_SYM : op == RW_INV_GEN ? RWW_INV_GEN : RWW_DET_GEN;
+}
+
+// form of the kernel: rowwave_choice (nfm_rowwave.hpp); NFM_ROWWAVE_ROWS (1 / 2 / 4) and
+// NFM_ROWWAVE_LDS (0 / 1) override it for the side-by-side measurements
+template <typename T, int N, int OP>
+static int launch(const void *a, const void *b, void *o, int64_t n, const RowParams &p, void *stream)
+{
+    static const int rows = [] { const char *e = getenv("NFM_ROWWAVE_ROWS"); return e ? atoi(e) : 0; }();
+    static const int ldsb = [] { const char *e = getenv("NFM_ROWWAVE_LDS"); return e ? atoi(e) : -1; }();
+    constexpr RwChoice c = rowwave_choice(sizeof(T) == 8, N, rww_of(OP));
+    const int r = rows ? rows : (c.rows ? c.rows : 2);
+    const bool lb = ldsb >= 0 ? ldsb != 0 : c.lds;
+    if (lb) {
+        if (r == 1) return launch_r<T, N, OP, 1, true>(a, b, o, n, p, stream);
+        if (r == 4) return launch_r<T, N, OP, 4, true>(a, b, o, n, p, stream);
+        return launch_r<T, N, OP, 2, true>(a, b, o, n, p, stream);
+    }
+    if (r == 1) return launch_r<T, N, OP, 1, false>(a, b, o, n, p, stream);
+    if (r == 4) return launch_r<T, N, OP, 4, false>(a, b, o, n, p, stream);
+    return launch_r<T, N, OP, 2, false>(a, b, o, n, p, stream);
 }
 
 #define NFM_RW_SWITCH(Nexpr, ...)                                                                  \
@@ -426,17 +550,12 @@ template struct RowWave<double>;
 #else
 template struct RowWave<float>;
 
-// defaults: measured cross-over orders (profiles/r02/rowwave_table.md)
-int rowwave_min_order(int is_f64, int what)
+bool rowwave_forced(bool f64, int N)
 {
     static const int env64 = [] { const char *e = getenv("NFM_ROWWAVE_MIN_F64"); return e ? atoi(e) : 0; }();
     static const int env32 = [] { const char *e = getenv("NFM_ROWWAVE_MIN_F32"); return e ? atoi(e) : 0; }();
-    if (what == RWW_INVDIAG_SYM) return 9;
-    if (is_f64 ? env64 : env32) return is_f64 ? env64 : env32;
-    //                                   solve inv_sym diag det_sym inv_gen det_gen
-    static const int min64[6] = {14, 14, 9, 15, 13, 13};
-    static const int min32[6] = {17, 17, 9, 17, 15, 17};
-    return is_f64 ? min64[what] : min32[what];
+    const int m = f64 ? env64 : env32;
+    return m > 0 && N >= m;
 }
 #endif
 

@@ -20,17 +20,46 @@ struct RowWave {
     static int batch_det(int N, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream);
 };
 
-// Which (dtype, order) pairs go to the row-wave kernels first (measured, profiles/r02/rowwave_table.md):
-// the lane-per-matrix kernels win while a matrix fits the register file with room to spare.
-// NFM_ROWWAVE_MIN_F64 / _F32 (environment, read once) override the thresholds for experiments.
-// what: which op asks (the cross-over order differs per op and dtype); the diagonal of the compact
-// inverse has no lane-per-matrix kernel beyond order 8, so the row-wave kernel takes every order 9..16
+// Which cases the row-wave kernels serve, and in which form (measured on MI355X,
+// profiles/r02/rowwave_table.md: every op x order 9..16 x dtype x {lane-per-matrix, 1 / 2 / 4 rows
+// per lane, pivot row through ds_bpermute or through an LDS slot}).  rows == 0: the lane-per-matrix
+// register kernel of nfm_large.hip is faster and keeps the case.  Cases listed here are NOT
+// instantiated in nfm_large.hip any more (they were the kernels that needed scratch memory:
+// float64 solve 13..16, inverses 12..16, determinants 14..16; float32 batchdet 16).
 enum { RWW_SOLVE = 0, RWW_INV_SYM, RWW_INVDIAG_SYM, RWW_DET_SYM, RWW_INV_GEN, RWW_DET_GEN };
-int rowwave_min_order(int dtype_is_f64, int what);
+struct RwChoice {
+    int rows;  // rows per lane (16 / rows lanes per matrix); 0 = not a row-wave case
+    bool lds;  // pivot row through an LDS slot instead of ds_bpermute
+};
+constexpr RwChoice rowwave_choice(bool f64, int N, int what)
+{
+    if (N < 9 || N > 16) return {0, false};
+    if (what == RWW_INVDIAG_SYM) return {(f64 && N >= 13) ? 2 : 4, false}; // no lane-per-matrix form exists
+    if (f64) {
+        switch (what) {
+        case RWW_SOLVE: return N >= 13 ? RwChoice{2, false} : N == 12 ? RwChoice{4, false} : RwChoice{0, false};
+        case RWW_INV_SYM: return N >= 13 ? RwChoice{2, false} : N >= 11 ? RwChoice{4, false} : RwChoice{0, false};
+        case RWW_DET_SYM: return N >= 14 ? RwChoice{2, false} : RwChoice{0, false};
+        case RWW_INV_GEN: return N >= 15 ? RwChoice{1, true} : N >= 11 ? RwChoice{2, false} : RwChoice{0, false};
+        case RWW_DET_GEN: return N >= 13 ? RwChoice{1, true} : RwChoice{0, false};
+        default: return {0, false};
+        }
+    }
+    switch (what) {
+    case RWW_INV_SYM: return N >= 13 ? RwChoice{4, false} : RwChoice{0, false};
+    case RWW_INV_GEN: return N >= 14 ? RwChoice{2, false} : RwChoice{0, false};
+    case RWW_DET_GEN: return N >= 16 ? RwChoice{2, false} : RwChoice{0, false};
+    default: return {0, false};
+    }
+}
+// run-time form for the dispatchers (nfm_sym.hip, nfm_batched.hip).  NFM_ROWWAVE_MIN_F64 / _F32
+// (environment, read once per process) force every order >= the value onto the row-wave kernels:
+// scripts/bench_rowwave.py uses it to time the forms side by side.
+bool rowwave_forced(bool f64, int N);
 template <typename T>
 inline bool rowwave_first(int N, int what)
 {
-    return N >= rowwave_min_order(sizeof(T) == 8, what);
+    return rowwave_choice(sizeof(T) == 8, N, what).rows != 0 || rowwave_forced(sizeof(T) == 8, N);
 }
 
 } // namespace nfm

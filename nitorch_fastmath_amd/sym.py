@@ -104,8 +104,10 @@ def _full_view(mat, N, kind):
 def _matvec_impl(mode, inp, mat, vec, dtype, out):
     dev, dtype, (inp, mat, vec) = _prep(dtype, inp, mat, vec)
     N = vec.shape[-1]
-    _check_order(N)
     kind = _mat_kind(mat.shape[-1], N)
+    if N > _lib.MAX_DIM:          # the reference's own large-order route, on the device (_bigorder.py)
+        from . import _bigorder
+        return _bigorder.sym_matvec(mode, inp, mat, vec, out, mat.shape[-1])
     matv, mat_nc = _full_view(mat, N, kind)
     shapes = [mat.shape[:-1], vec.shape[:-1]] + ([inp.shape[:-1]] if inp is not None else [])
     batch = broadcast_shapes(*shapes)
@@ -215,8 +217,10 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
         return SymSolveFn.apply(torch.as_tensor(mat), torch.as_tensor(vec), eps, dtype)
     dev, dtype, (mat, vec) = _prep(dtype, mat, vec)
     N = vec.shape[-1]
-    _check_order(N)
     kind = _mat_kind(mat.shape[-1], N)
+    if N > _lib.MAX_DIM:          # densify + torch.linalg.solve on the device, as `_impl/sym.py:392-396`
+        from . import _bigorder
+        return _bigorder.sym_solve(mat, vec, eps, out, mat.shape[-1])
     matv, mat_nc = _full_view(mat, N, kind)
     batch = broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
     out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if N <= 8 else None)
@@ -263,7 +267,9 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
         return SymInvertFn.apply(torch.as_tensor(mat), bool(diag), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])
-    _check_order(M)
+    if M > _lib.MAX_DIM:
+        from . import _bigorder
+        return _bigorder.sym_invert(mat, M, bool(diag), out)
     batch = mat.shape[:-1]
     out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=mat if M <= 8 else None)
     b = Batch(batch, [mat, out], [1, 1], pack=M > 8 and not diag)
@@ -294,7 +300,9 @@ def sym_det(mat, dtype=None, out=None):
         return SymDetFn.apply(torch.as_tensor(mat), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])
-    _check_order(M)
+    if M > _lib.MAX_DIM:
+        from . import _bigorder
+        return _bigorder.sym_det(mat, M, out)
     batch = mat.shape[:-1]
     out, _ = _alloc_out(out, tuple(batch), dtype, dev)
     b = Batch(batch, [mat, out], [1, 0], pack=M > 8)
@@ -320,7 +328,9 @@ def sym_to_full(mat, dtype=None, out=None):
         return SymToFullFn.apply(torch.as_tensor(mat), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])
-    _check_order(M)
+    if M > _lib.MAX_DIM:
+        from . import _bigorder
+        return _bigorder._deliver(_bigorder.to_full(mat, M), out)
     batch = mat.shape[:-1]
     out, _ = _alloc_out(out, tuple(batch) + (M, M), dtype, dev)
     b = Batch(batch, [mat, out], [1, 2])

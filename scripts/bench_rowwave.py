@@ -57,8 +57,11 @@ def main():
     if '--arm' in sys.argv:
         return arm()
     res = {}
-    for name, v in (('lane', '17'), ('row', '9')):
-        env = dict(os.environ, NFM_ROWWAVE_MIN_F64=v, NFM_ROWWAVE_MIN_F32=v)
+    # (name, minimum order of the row-wave path, rows per lane, pivot row broadcast through LDS)
+    arms = (('lane', '17', '0', '0'), ('r1 bperm', '9', '1', '0'), ('r2 bperm', '9', '2', '0'), ('r4 bperm', '9', '4', '0'),
+            ('r1 lds', '9', '1', '1'), ('r2 lds', '9', '2', '1'), ('r4 lds', '9', '4', '1'))
+    for name, v, rows, lds in arms:
+        env = dict(os.environ, NFM_ROWWAVE_MIN_F64=v, NFM_ROWWAVE_MIN_F32=v, NFM_ROWWAVE_ROWS=rows, NFM_ROWWAVE_LDS=lds)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--arm'], env=env, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-3000:])
@@ -67,12 +70,16 @@ def main():
             if '|' in line:
                 k, n, b, ms = line.split('|')
                 res.setdefault(k, {})[name] = (int(n), int(b), float(ms))
-    print('| op order dtype | batch | B/unit | lane-per-matrix ms | TB/s | 16-lanes-per-matrix ms | TB/s | row/lane speed-up |')
-    print('|---|---|---|---|---|---|---|---|')
+    names = [a[0] for a in arms]
+    print('TB/s of algorithmic bytes; lane = one matrix per lane (nfm_large.hip); rK = K rows per lane, 16/K lanes per '
+          'matrix (nfm_rowwave.hip), pivot row broadcast by ds_bpermute or through an LDS slot\n')
+    print('| op order dtype | batch | B/unit | ' + ' | '.join(names) + ' | best |')
+    print('|---|---|---|' + '---|' * (len(names) + 1))
     for k, v in res.items():
-        n, b, tl = v['lane']
-        tr = v['row'][2]
-        print(f'| {k} | {n:.2e} | {b} | {tl:.3f} | {n * b / tl / 1e9:.2f} | {tr:.3f} | {n * b / tr / 1e9:.2f} | {tl / tr:.2f} |')
+        n, b, _ = v['lane']
+        tb = {a: n * b / v[a][2] / 1e9 for a in v}
+        best = max(tb, key=tb.get)
+        print(f"| {k} | {n:.2e} | {b} | " + ' | '.join(f'{tb[a]:.2f}' for a in names) + f' | {best} |')
 
 
 if __name__ == '__main__':

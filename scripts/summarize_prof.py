@@ -33,10 +33,12 @@ def main():
         for r in rows:
             k = trim(r['Kernel_Name'])
             seen.setdefault(k, r)
-        lines += ['', '| nfm kernel | VGPR | SGPR | LDS B/block | scratch | workgroup | grid |', '|---|---|---|---|---|---|---|']
+        lines += ['', '| nfm kernel | workgroup | grid |', '|---|---|---|']
         for k, r in seen.items():
-            lines.append(f"| `{k}` | {r['VGPR_Count']} | {r['SGPR_Count']} | {r['LDS_Block_Size']} | {r['Scratch_Size']} | "
-                         f"{r['Workgroup_Size_X']} | {r['Grid_Size_X']}x{r['Grid_Size_Y']} |")
+            lines.append(f"| `{k}` | {r['Workgroup_Size_X']} | {r['Grid_Size_X']}x{r['Grid_Size_Y']} |")
+        lines += ['', 'registers / LDS / scratch per kernel: profiles/r02/kernel_resources.md (read from the code objects by '
+                  'scripts/kernel_resources.py; the VGPR_Count / LDS_Block_Size columns of the rocprofv3 trace are not the '
+                  'allocation -- they report 20-32 VGPRs and 0 LDS for kernels that allocate 61 and use dynamic LDS)']
         durs = {}
         for r in rows:
             durs.setdefault(trim(r['Kernel_Name']), []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))

@@ -231,3 +231,35 @@ def test_signatures_match_the_reference():
     assert names(N.reduce.nansum) == ['input', 'dim', 'keepdim', 'inplace', 'dtype', 'out']                   # reduce.py:471-478
     assert names(N.reduce.var) == ['input', 'dim', 'keepdim', 'unbiased', 'omitnan', 'inplace', 'dtype', 'out']  # reduce.py:597-606
     assert names(N.reduce.nanstd) == ['input', 'dim', 'keepdim', 'unbiased', 'inplace', 'dtype', 'out']       # reduce.py:729-737
+
+
+def test_no_scratch_outside_the_run_time_order_qr_kernels():
+    """Code-object facts (scripts/kernel_resources.py reads the `amdhsa.kernels` notes of the built
+    objects): no sym / batched / reduce kernel uses scratch memory -- "one matrix per lane held
+    entirely in registers", and where a matrix does not fit a lane's 512 registers (float64
+    orders 13..16) the one-matrix-per-16-lanes kernels of nfm_rowwave.hip, which do.  The only
+    kernels with a private segment are the run-time-order QR kernels for orders 9..16
+    (`qr_generic_kernel`, beyond the orders the reference's QR runs at all) and the 8x8 float64
+    `rq_hessenberg` with eigenvector accumulation in its mixed-layout form."""
+    import glob
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    try:
+        import kernel_resources as KR
+    finally:
+        sys.path.pop(0)
+    objs = sorted(glob.glob(os.path.join(ROOT, 'nitorch_fastmath_amd', 'csrc', '*.o')))
+    if not objs:
+        pytest.skip('objects not built in this checkout (the .so alone travels to the GPU box)')
+    rows = KR.collect(objs)
+    assert len(rows) > 1000
+    bad = [k['kernel'] for k in rows if k['scratch'] and 'qr_generic_kernel' not in k['kernel']
+           and 'RqHessOp<double, 8, true>, 0>' not in k['kernel']]
+    assert not bad, bad[:5]
+    by = {k['kernel']: k for k in rows}
+    # the bench kernels: registers as quoted in DESIGN.md section 4
+    assert by['rec_kernel<float, SolveOp<float, 4, 0>, 1>']['vgpr'] <= 64          # 8 waves / SIMD
+    assert by['rec_kernel<float, SolveOp<float, 6, 0>, 1>']['vgpr'] <= 64
+    assert by['rec_kernel<double, BatchInvOp<double, 8>, 1>']['vgpr'] <= 256       # 2 waves / SIMD
+    rw = [k for k in rows if 'roww_kernel' in k['kernel']]
+    assert rw and max(k['vgpr'] for k in rw) <= 256 and not any(k['scratch'] for k in rw)

@@ -140,3 +140,29 @@ def test_rowwave_ragged_tiles_f64(dev, oracle, M):
     z = np.zeros((5, M, M))
     assert not np.isfinite(B.batchinv(t(z, dev)).cpu().numpy()).any()
     assert (B.batchdet(t(z, dev)).cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_orders_above_16_take_the_references_route_on_device(dev, dn):
+    """orders > 16 are outside the kernels (`NFM_MAX_DIM`); the facade then does what the reference
+    does for every order > 4: densify and call torch.linalg on the device (`_impl/sym.py:392-396`,
+    `_impl/batched.py:119-120`) -- no ValueError, no CPU round trip"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    tol = 2e-5 if dn == 'f32' else 1e-11
+    M, n = 20, 37
+    mat, vec = spd_np(n, M, dtype, 9)
+    S, B = N().sym, N().batched
+    full = S.sym_to_full(t(mat, dev))
+    assert full.shape == (n, M, M) and torch.equal(full, full.transpose(-1, -2))
+    f64 = full.double().cpu().numpy()
+    x = S.sym_solve(t(mat, dev), t(vec, dev))
+    assert x.is_cuda and relerr(x.cpu().numpy(), np.linalg.solve(f64, vec.astype(np.float64)[..., None])[..., 0]) <= tol
+    assert relerr(S.sym_matvec(t(mat, dev), t(vec, dev)).cpu().numpy(), np.einsum('bij,bj->bi', f64, vec)) <= tol
+    inv = S.sym_invert(t(mat, dev))
+    assert inv.shape == mat.shape
+    assert relerr(S.sym_to_full(inv).cpu().numpy(), np.linalg.inv(f64)) <= tol
+    assert relerr(S.sym_invert(t(mat, dev), diag=True).cpu().numpy(), np.diagonal(np.linalg.inv(f64), axis1=1, axis2=2)) <= tol
+    assert relerr(S.sym_det(t(mat, dev)).cpu().numpy(), np.linalg.det(f64)) <= 10 * tol
+    a = t(f64.astype(dtype), dev)
+    assert relerr(B.batchinv(a).cpu().numpy(), np.linalg.inv(f64)) <= tol
+    assert relerr(B.batchdet(a).cpu().numpy(), np.linalg.det(f64)) <= 10 * tol

@@ -233,8 +233,11 @@ def test_empty_and_errors(dev):
         S.sym_invert(torch.zeros(5, 7, device=dev))
     with pytest.raises(TypeError):
         S.sym_solve(torch.zeros(5, 10, device=dev, dtype=torch.half), torch.zeros(5, 4, device=dev, dtype=torch.half))
-    with pytest.raises(ValueError):
-        S.sym_solve(torch.zeros(5, 17 * 9, device=dev), torch.zeros(5, 17, device=dev))
+    # order 17 (K = 153): beyond the kernels, served by torch.linalg on the device like upstream
+    r17 = S.sym_solve(torch.eye(17, device=dev)[None].expand(5, 17, 17)[..., :1].new_ones(5, 153) * 0 +
+                      torch.cat([torch.ones(5, 17, device=dev), torch.zeros(5, 136, device=dev)], -1),
+                      torch.arange(17., device=dev).expand(5, 17))
+    assert torch.equal(r17, torch.arange(17., device=dev).expand(5, 17))
     # singular input -> inf/nan like the reference, no error
     r = S.sym_solve(torch.zeros(4, 10, device=dev), torch.ones(4, 4, device=dev))
     assert not torch.isfinite(r).any()
