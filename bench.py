@@ -160,6 +160,7 @@ class Workload:
     """name, unit count per step, algorithmic bytes per unit, the step closure, the parity check, the cpu leg."""
     output = None
     cpu_eager = None
+    eager_sizes = (0, 0)
 
 
 def make_workload(name, n_arg, device, rank, layout):
@@ -210,18 +211,8 @@ def make_workload(name, n_arg, device, rank, layout):
             return time_cpu(lambda: O.sym_solve(m_h, v_h), ns, budget_s), f'first {ns:.0e} systems of the GPU batch'
         w.cpu = cpu
         if M == 4:
-            def cpu_eager(threads, ns):
-                from oracle import torch_eager as T
-                ns = min(n, ns)
-                m_h, v_h = mat[:ns].contiguous().cpu(), vec[:ns].contiguous().cpu()
-                old = torch.get_num_threads()
-                torch.set_num_threads(threads)
-                try:
-                    rate = time_cpu(lambda: T.sym_solve(m_h, v_h), ns, 0.0, reps_min=1)
-                finally:
-                    torch.set_num_threads(old)
-                return rate, ns
-            w.cpu_eager = cpu_eager
+            w.cpu_eager = eager_timer(lambda ns: (mat[:ns].contiguous().cpu(), vec[:ns].contiguous().cpu()), 'sym_solve', n)
+            w.eager_sizes = (2_000_000, 10_000_000)
     elif name == 'sym_invert3':
         n = int(n_arg or 1e5)
         mat, _ = spd_compact(n, 3, torch.float64, device, seed)
@@ -245,6 +236,8 @@ def make_workload(name, n_arg, device, rank, layout):
             m_h = mat.cpu().numpy()
             return time_cpu(lambda: O.sym_invert(m_h), n, budget_s), 'the whole batch'
         w.cpu = cpu
+        w.cpu_eager = eager_timer(lambda ns: (mat[:ns].cpu(),), 'sym_invert', n)
+        w.eager_sizes = (n, n)
     elif name == 'eig3':
         n = int(n_arg or 5e7)
         g = torch.Generator(device=device).manual_seed(seed)
@@ -309,6 +302,8 @@ def make_workload(name, n_arg, device, rank, layout):
             a_h = a[:ns].cpu().numpy()
             return time_cpu(lambda: O.batch_inv(a_h), ns, budget_s), f'first {ns:.0e} matrices'
         w.cpu = cpu
+        w.cpu_eager = eager_timer(lambda ns: (a[:ns].cpu(),), 'batch_inv', n)
+        w.eager_sizes = (200_000, 2_000_000)
     elif name in ('nansum', 'nanmax'):
         n = int(n_arg or 2 ** 33)       # 32 GiB fp32
         g = torch.Generator(device=device).manual_seed(seed)
@@ -355,9 +350,30 @@ def make_workload(name, n_arg, device, rank, layout):
             x_h = x[:ns].cpu().numpy()
             return time_cpu(lambda: O.reduce(name, x_h), ns, budget_s), f'first {ns * 4 / 2 ** 30:.0f} GiB'
         w.cpu = cpu
+        w.cpu_eager = eager_timer(lambda ns: (x[:ns].cpu(),), name, n)
+        w.eager_sizes = (1 << 26, 1 << 28)
     else:
         raise SystemExit(f'unknown workload {name}')
     return w
+
+
+def eager_timer(make_inputs, fn_name, n):
+    """cpu_baseline.torch_eager leg: the reference's CPU op sequence restated in eager torch
+    (oracle/torch_eager.py), timed at a given thread count on the first `ns` units"""
+    def run(threads, ns):
+        import torch
+        from oracle import torch_eager as T
+        ns = min(n, ns)
+        inputs = make_inputs(ns)
+        fn = getattr(T, fn_name)
+        old = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        try:
+            rate = time_cpu(lambda: fn(*inputs), ns, 0.0, reps_min=1)
+        finally:
+            torch.set_num_threads(old)
+        return rate, ns
+    return run
 
 
 def host_cores():
@@ -577,12 +593,14 @@ def run_rank(a):
             # the reference's own cost shape (component-first, ~270 full-batch ATen ops with n-sized
             # temporaries per 4x4 solve), restated in eager torch: 1 thread and all threads
             from oracle import torch_eager as T
-            r1, n1 = w.cpu_eager(1, 2_000_000)
-            ra, na = w.cpu_eager(avail, 10_000_000)
+            r1, n1 = w.cpu_eager(1, w.eager_sizes[0])
+            ra, na = w.cpu_eager(avail, w.eager_sizes[1])
             line['cpu_baseline']['torch_eager'] = {
-                'k1': r1, 'kall': ra, 'cores_all': avail, 'unit': w.unit, 'ops_per_call': T.ops_per_call(4),
-                'sample': f'first {n1:.0e} (1 thread) / {na:.0e} ({avail} threads) systems, best of 1 run after warm-up',
+                'k1': r1, 'kall': ra, 'cores_all': avail, 'unit': w.unit,
+                'sample': f'first {n1:.0e} (1 thread) / {na:.0e} ({avail} threads) units, best of 1 run after warm-up',
                 'note': 'oracle/torch_eager.py: eager restatement of the reference CPU op sequence, pinned to tests/golden'}
+            if a.workload == 'sym_solve4':
+                line['cpu_baseline']['torch_eager']['ops_per_call'] = T.ops_per_call(4)
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -39,7 +39,7 @@ __device__ __forceinline__ void to_mat(const T (&r)[N * N], T (&a)[N][N], int mi
         }
 }
 
-// FAST: float32 sweep arithmetic of nfm_qr_core.hpp (FastSweeps); false = reference-order IEEE
+// FAST: fast sweep arithmetic of nfm_qr_core.hpp (FastSweeps); false = reference-order IEEE
 template <typename T, int N, bool WITH_U, bool FAST = false>
 struct EigSymOp {
     using RA = Rec<N, N>;

@@ -41,15 +41,16 @@ __device__ __forceinline__ bool finite_(T x)
 //
 // IEEE division and square root are software sequences on gfx950 (v_div_scale x2, v_rcp,
 // 4 fma, v_div_fmas, v_div_fixup; v_sqrt + fix-up), a third of the instructions of a sweep.
-// For float32 the sweeps use the hardware approximations instead, refined where the value
+// The fast sweeps use the hardware approximations instead, refined where the value
 // enters the result: a rotation is (c, s) = (x, -y) * rsqrt(x^2 + y^2) with one Newton step
 // on v_rsq_f32 (relative error <= ~1 ulp, i.e. the same as the reference's sqrt followed by
 // two divisions), products and sums contract to fma (each fma rounds once where the
 // reference rounds twice).  The Wilkinson shift and the convergence ratio only steer the
 // iteration -- ANY shift gives a similarity transform -- so they use v_sqrt_f32 / v_rcp_f32
 // unrefined.  Arguments outside [2^-100, 2^100] (zeros, denormal squares, inf, NaN) take the
-// IEEE path, so the special values behave exactly as before.  float64 keeps the IEEE path:
-// v_rcp_f64 / v_rsq_f64 deliver ~26 bits and two Newton steps cost what the division does.
+// IEEE path, so the special values behave exactly as before.  float64 does the same with two
+// Newton steps on v_rsq_f64 (~26 bits): 11 instructions for a rotation against ~50 for the IEEE
+// square root and two divisions.
 //
 // What the fast sweeps change is rounding, not accuracy (measured against numpy.linalg.eigvalsh
 // in float64: within 2x the error of the reference-order arithmetic at every order,
@@ -61,11 +62,7 @@ __device__ __forceinline__ bool finite_(T x)
 // Error model and its tests: tests/test_gpu_qr.py.
 template <typename T>
 struct FastSweeps {
-    static constexpr bool on = false;
-};
-template <>
-struct FastSweeps<float> {
-    static constexpr bool on = true;
+    static constexpr bool on = true; // both dtypes; FAST (a template argument of the callers) selects it
 };
 
 __device__ __forceinline__ float rsq_nr(float x)
@@ -74,31 +71,63 @@ __device__ __forceinline__ float rsq_nr(float x)
     const float h = (0.5f * x) * r;
     return __builtin_fmaf(r, __builtin_fmaf(-h, r, 0.5f), r); // r (1.5 - 0.5 x r^2)
 }
+__device__ __forceinline__ double rsq_nr(double x)
+{
+    double r = __builtin_amdgcn_rsq(x); // ~26 bits: two Newton steps
+    const double hx = 0.5 * x;
+    r = __builtin_fma(r, __builtin_fma(-(hx * r), r, 0.5), r);
+    return __builtin_fma(r, __builtin_fma(-(hx * r), r, 0.5), r);
+}
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float copysign_t(float a, float b) { return __builtin_copysignf(a, b); }
+__device__ __forceinline__ double copysign_t(double a, double b) { return __builtin_copysign(a, b); }
+__device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double hw_sqrt(double x) { return x * rsq_nr(x); }
+__device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double hw_rcp(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r); // one step: ~50 bits, the value only steers
+}
+// safe range of the squared magnitudes for the hardware approximations (no denormals, no overflow)
+template <typename T>
+struct FastRange;
+template <>
+struct FastRange<float> {
+    static constexpr float lo = 0x1p-100f, hi = 0x1p100f;
+};
+template <>
+struct FastRange<double> {
+    static constexpr double lo = 0x1p-900, hi = 0x1p900;
+};
 
 // _givens_jit :326-334
 template <typename T>
 __device__ __forceinline__ void givens1(T x, T y, T &c, T &s);
 
-// float32 sweep form of the same rotation (policy above)
-__device__ __forceinline__ void givens_fast1(float x, float y, float &c, float &s)
+// sweep form of the same rotation (policy above)
+template <typename T>
+__device__ __forceinline__ void givens_fast1(T x, T y, T &c, T &s)
 {
-    const float r2 = __builtin_fmaf(x, x, y * y);
-    if (__builtin_expect(!(r2 > 0x1p-100f && r2 < 0x1p100f), 0)) {
-        givens1<float>(x, y, c, s);
+    const T r2 = fma_t(x, x, y * y);
+    if (__builtin_expect(!(r2 > FastRange<T>::lo && r2 < FastRange<T>::hi), 0)) {
+        givens1<T>(x, y, c, s);
         return;
     }
-    const float inv = rsq_nr(r2);
+    const T inv = rsq_nr(r2);
     // an axis-aligned pair is an exact rotation in the reference (x / |x| = +-1): keep it exact, so
     // that diagonal / already deflated input comes back bit for bit
-    c = (y == 0.0f) ? __builtin_copysignf(1.0f, x) : x * inv;
-    s = (x == 0.0f) ? -__builtin_copysignf(1.0f, y) : -(y * inv);
+    c = (y == T(0)) ? copysign_t(T(1), x) : x * inv;
+    s = (x == T(0)) ? -copysign_t(T(1), y) : -(y * inv);
 }
 
-__device__ __forceinline__ void rot_fast1(float &a0, float &a1, float c, float s)
+template <typename T>
+__device__ __forceinline__ void rot_fast1(T &a0, T &a1, T c, T s)
 {
-    const float t = s * a0;
-    a0 = __builtin_fmaf(a0, c, -(s * a1));
-    a1 = __builtin_fmaf(a1, c, t);
+    const T t = s * a0;
+    a0 = fma_t(a0, c, -(s * a1));
+    a1 = fma_t(a1, c, t);
 }
 
 template <typename T>
@@ -346,16 +375,70 @@ __device__ __forceinline__ T wilkinson1(T h0, T h1, T b)
     return h1 - s * b2 / d;
 }
 
-// the same shift for the float32 sweeps: hardware sqrt / rcp, unrefined (a shift only steers)
-__device__ __forceinline__ float wilkinson_fast1(float h0, float h1, float b)
+// the same shift for the fast sweeps: hardware sqrt / rcp (a shift only steers the iteration)
+template <typename T>
+__device__ __forceinline__ T wilkinson_fast1(T h0, T h1, T b)
 {
-    const float b2 = b * b;
-    float d = (h0 - h1) * 0.5f;
-    const float sb2 = (d < 0.0f) ? -b2 : b2;
-    const float t = __builtin_fmaf(d, d, b2);
-    if (__builtin_expect(!(t > 0x1p-100f && t < 0x1p100f), 0)) return wilkinson1<float>(h0, h1, b);
-    d = fabs_(d) + __builtin_amdgcn_sqrtf(t);
-    return h1 - sb2 * __builtin_amdgcn_rcpf(d);
+    const T b2 = b * b;
+    T d = (h0 - h1) * T(0.5);
+    const T sb2 = (d < T(0)) ? -b2 : b2;
+    const T t = fma_t(d, d, b2);
+    if (__builtin_expect(!(t > FastRange<T>::lo && t < FastRange<T>::hi), 0)) return wilkinson1<T>(h0, h1, b);
+    d = fabs_(d) + hw_sqrt(t);
+    return h1 - sb2 * hw_rcp(d);
+}
+
+// One explicitly shifted QR step T <- R Q + sigma on the leading m x m block of a SYMMETRIC
+// TRIDIAGONAL matrix, the fast sweeps' form of `rq_step1(..., sym = true)`: the same rotations
+// (c_k, s_k) and, in exact arithmetic, the same T' -- but only the diagonal and the sub-diagonal
+// are carried (11 operations per rotation instead of six 4-operation row / column rotations):
+//   p_0 = d_0 - sigma, q_0 = e_0;   (C_k, S_k, r_k) rotate (p_k, e_k) onto (r_k, 0);
+//   u_k = C_k q_k + S_k (d_{k+1} - sigma);   p_{k+1} = C_k (d_{k+1} - sigma) - S_k q_k;   q_{k+1} = C_k e_{k+1};
+//   d'_k = C_{k-1} C_k r_k + S_k u_k + sigma;   e'_{k-1} = S_{k-1} r_k;   d'_{m-1} = C_{m-2} p_{m-1} + sigma.
+// (derivation and a numerical check against the explicit form: DESIGN.md section 4.2).  The upper
+// sub-diagonal is kept equal to the lower one so that the storage stays a symmetric matrix.
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void tri_sweep_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                                T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m, T sigma)
+{
+    constexpr int MX = Dim<NT>::MAX;
+    T p = h[0][0] - sigma, q = h[1][0];
+    T cprev = T(1), sprev = T(0);
+#pragma unroll
+    for (int k = 0; k < MX - 1; ++k) {
+        if (k < m - 1) {
+            const T b = h[k + 1][k];
+            const T a1 = h[k + 1][k + 1] - sigma;
+            T c, sr; // the reference's convention: sr = -S
+            givens_fast1(p, b, c, sr);
+            const T S = -sr;
+            const T r = fma_t(c, p, S * b);
+            const T uk = fma_t(c, q, S * a1);
+            const T pn = fma_t(c, a1, -(S * q));
+            T qn = T(0);
+            if (k + 2 < MX)
+                if (k + 2 < m) qn = c * h[k + 2][k + 1];
+            h[k][k] = fma_t(c * cprev, r, S * uk) + sigma;
+            if (k > 0) {
+                const T e = sprev * r;
+                h[k][k - 1] = e;
+                h[k - 1][k] = e;
+            }
+            if (WITH_U) {
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < n) rot_fast1(u[i][k], u[i][k + 1], c, sr);
+            }
+            p = pn;
+            q = qn;
+            cprev = c;
+            sprev = S;
+        }
+    }
+    const T e = sprev * p;
+    h[m - 1][m - 1] = fma_t(cprev, p, sigma);
+    h[m - 1][m - 2] = e;
+    h[m - 2][m - 1] = e;
 }
 
 // _qr_explicit(_vectors)_jit_ :572-656 with sym = True; convergence per lane (Q9)
@@ -380,11 +463,15 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                 T sigma;
                 if constexpr (FM) sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
                 else sigma = wilkinson1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
+                if constexpr (FM) {
+                    tri_sweep_fast1<T, NT, WITH_U>(h, u, n, m, sigma);
+                } else {
 #pragma unroll
-                for (int i = 0; i < m; ++i) h[i][i] -= sigma;
-                rq_step1<T, NT, WITH_U, FM>(h, u, n, m, true);
+                    for (int i = 0; i < m; ++i) h[i][i] -= sigma;
+                    rq_step1<T, NT, WITH_U, false>(h, u, n, m, true);
 #pragma unroll
-                for (int i = 0; i < m; ++i) h[i][i] += sigma;
+                    for (int i = 0; i < m; ++i) h[i][i] += sigma;
+                }
                 const T bb = fabs_(h[m - 1][m - 2]), a0 = fabs_(h[m - 1][m - 1]), a1 = fabs_(h[m - 2][m - 2]);
                 const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
                 // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
@@ -399,7 +486,7 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                     // |prev - new| / prev < tol * 1e-3, written without the fp64 division (prev > 0)
                     double sos_new;
                     if constexpr (FM) // the ratio only detects a fixed point of the iteration
-                        sos_new = (double)(sos_lower * __builtin_amdgcn_rcpf(sos_diag));
+                        sos_new = (double)(sos_lower * hw_rcp(sos_diag));
                     else sos_new = (double)(sos_lower / sos_diag);
                     const double dif = sos_prev - sos_new;
                     if (sos_prev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sos_prev) break;

@@ -16,12 +16,12 @@ raises for batched n > 5); `rq_hessenberg` returns the true R Q for any Hessenbe
 own deflation order, i.e. what upstream returns when called on that matrix alone (its order
 for a batch depends on the other matrices in the batch).
 
-float32 `eig_sym` has two arithmetic modes (`arithmetic=`, default `SWEEP_ARITHMETIC`):
-`'fast'` runs the QR sweeps on v_rsq_f32 + one Newton step with fma contraction (2x the
-throughput, the same accuracy against the exact eigenvalues, but the deflation ORDER and the
-eigenvector SIGNS -- both unspecified upstream -- can differ from the reference's);
+`eig_sym` has two arithmetic modes (`arithmetic=`, default `SWEEP_ARITHMETIC`):
+`'fast'` runs the QR sweeps on v_rsq + Newton steps with fma contraction (2x the throughput,
+the same accuracy against the exact eigenvalues, but the deflation ORDER and the eigenvector
+SIGNS -- both unspecified upstream -- can differ from the reference's);
 `'reference'` keeps the reference's operation order with IEEE division and square root and
-reproduces the CPU path bit for bit.  float64 always runs `'reference'`.
+reproduces the CPU path bit for bit.
 """
 __all__ = [
     'eig_sym',
@@ -40,7 +40,7 @@ from . import _lib
 from ._dispatch import Batch, dtype_code, expand_batch, no_grad_required, require_gpu, stream_ptr, broadcast_shapes
 from .utils import ensure_list
 
-# default arithmetic of the float32 QR sweeps of eig_sym: 'fast' or 'reference' (module docstring)
+# default arithmetic of the QR sweeps of eig_sym: 'fast' or 'reference' (module docstring)
 SWEEP_ARITHMETIC = 'fast'
 
 
@@ -112,8 +112,8 @@ def eig_sym(a, compute_u=False, upper=True, inplace=False, check_finite=True, ma
     max_iter : `int`, default=1024
     tol : `float`, default=1e-32
     arithmetic : `{'fast', 'reference'}`, keyword-only, default=`SWEEP_ARITHMETIC`
-        float32 only (extension, see the module docstring): `'reference'` reproduces the
-        reference CPU path bit for bit (deflation order and eigenvector signs included).
+        extension, see the module docstring: `'reference'` reproduces the reference CPU path bit
+        for bit (deflation order and eigenvector signs included).
 
     Returns
     -------

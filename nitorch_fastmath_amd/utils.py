@@ -63,8 +63,12 @@ class graphed:
 
     Small batches (the reference's 1e5-matrix configuration, Gauss-Newton inner loops over a
     few thousand voxels) spend 15-30 us per call on the host for kernels of a few us; a graph
-    replays the whole captured sequence with one launch.  The entry points of this backend never
-    allocate or synchronise, so any composition of them captures.
+    replays the whole captured sequence with one launch.  The C entry points never allocate or
+    synchronise, so any composition of them captures -- with two facade-level exceptions, both host
+    reads that cannot be recorded into a graph: the `qr` functions must be called with
+    `check_finite=False` (their default `check_finite=True` runs `torch.isfinite(a).all()` and
+    reads the result on the host), and reductions must not be read back (`float(nansum(x))`)
+    inside the captured function.
 
         step = graphed(lambda h, g: sym_solve(h, g), hess, grad)   # captures once (static buffers)
         x = step(hess_new, grad_new)                                # copies in, replays, returns outputs

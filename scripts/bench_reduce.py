@@ -50,7 +50,7 @@ if 'reduce' in which:
             rows.append((f'{name} ({o},{r},{i}) dim=1', total, b / total, t))
     del x
 if 'qr' in which:
-    for dtype, dn, sz in ((torch.float32, 'f32', 4),):
+    for dtype, dn, sz in ((torch.float32, 'f32', 4), (torch.float64, 'f64', 8)):
         n = 1 << 24
         g = torch.Generator(device=dev).manual_seed(1)
         a = torch.randn(n, device=dev, generator=g, dtype=dtype)
@@ -71,6 +71,8 @@ if 'qr' in which:
                          timeit(lambda: N.eig_sym(S, check_finite=False), reps=3)))
             rows.append((f'eig_sym {M}x{M} {dn} vectors', n, (2 * M * M + M) * sz,
                          timeit(lambda: N.eig_sym(S, compute_u=True, check_finite=False), reps=3)))
+            rows.append((f"eig_sym {M}x{M} {dn} values, arithmetic='reference'", n, (M * M + M) * sz,
+                         timeit(lambda: N.eig_sym(S, check_finite=False, arithmetic='reference'), reps=3)))
             del A, S, v, H
 print('| op | units | B/unit | ms | units/s | GB/s | frac of 8 TB/s |')
 print('|---|---|---|---|---|---|---|')

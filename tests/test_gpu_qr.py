@@ -128,7 +128,7 @@ def test_golden_sym_family(dev, golden_qr, dn, n):
     eye = np.broadcast_to(np.eye(n, dtype=a.dtype), a.shape).copy()
     h2, u2 = G.rq_hessenberg(g[k + 'tri'], eye)
     assert relerr(u2, g[k + 'rq_tri_u']) <= tol and relerr(h2, g[k + 'rq_tri']) <= tol
-    # the fast float32 sweeps: the same eigenvalues as a SET within the error model (order and signs
+    # the fast sweeps: the same eigenvalues as a SET within the error model (order and signs
     # are not specified upstream, `qr.py:45-46`), eigenpairs checked by their defining equations
     F = GpuQ(dev, 'fast')
     truth = np.linalg.eigvalsh(sym.astype(np.float64))
@@ -165,11 +165,10 @@ def test_vs_oracle(dev, oracle, dn, n):
     # reference-order arithmetic: the oracle's values in the oracle's order
     ev = n_(Q().eig_sym(sd, arithmetic='reference'))
     assert relerr(ev, ref) <= tol
-    # fast float32 sweeps (float64: the same kernel as above): the same set within the error model
+    # fast sweeps: the same set within the error model (float64: the truth is numpy.linalg in float64,
+    # itself good to a few n * eps, which the model's floor covers)
     evf = n_(Q().eig_sym(sd, arithmetic='fast'))
     assert within_model(np.sort(evf, -1), np.sort(ref, -1), truth, n, dn), relerr(np.sort(evf, -1), truth)
-    if dn == 'f64':
-        assert np.array_equal(evf, ev)
     for mode in ('reference', 'fast'):
         ev2, evec = Q().eig_sym(sd, compute_u=True, arithmetic=mode)
         check_eigenpairs(sym, n_(ev2), n_(evec), n, dn)
@@ -208,12 +207,13 @@ def test_layouts_and_errors(dev, oracle):
     sym = (a + a.swapaxes(-1, -2)) / 2
     ref = oracle.eig_sym(sym)
     sd = t(sym, dev)
-    assert relerr(n_(Q().eig_sym(sd)), ref) <= 1e-11
+    assert relerr(n_(Q().eig_sym(sd, arithmetic='reference')), ref) <= 1e-11
+    assert relerr(np.sort(n_(Q().eig_sym(sd)), -1), np.sort(ref, -1)) <= 1e-11          # default: fast sweeps
     # matrix-first ("channel-first") storage: (3, 3, B, X, Y) viewed as (B, X, Y, 3, 3)
     cf = sd.permute(3, 4, 0, 1, 2).contiguous().permute(2, 3, 4, 0, 1)
     assert not cf.is_contiguous()
-    assert relerr(n_(Q().eig_sym(cf)), ref) <= 1e-11
-    ev, evec = Q().eig_sym(cf[:, ::2], compute_u=True)
+    assert relerr(n_(Q().eig_sym(cf, arithmetic='reference')), ref) <= 1e-11
+    ev, evec = Q().eig_sym(cf[:, ::2], compute_u=True, arithmetic='reference')
     assert relerr(n_(ev), ref[:, ::2]) <= 1e-11 and evec.shape == (4, 5, 5, 3, 3)
     with pytest.raises(ValueError, match='non finite'):
         Q().eig_sym(torch.full((2, 3, 3), float('nan'), device=dev))

@@ -95,3 +95,20 @@ def test_graphed_helper_replays_a_sequence(dev):
     torch.cuda.synchronize()
     t_eager = (time.perf_counter() - t0) / 200
     assert t_graph < t_eager, (t_graph, t_eager)
+
+
+def test_qr_functions_capture_with_check_finite_off(dev):
+    """the qr facade's default `check_finite=True` reads `isfinite(a).all()` on the host and so cannot
+    be captured; with `check_finite=False` an eig_sym call is one launch and replays (utils.graphed
+    docstring)"""
+    from nitorch_fastmath_amd.utils import graphed
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randn(4096, 3, 3, device=dev, generator=g)
+    a = a + a.transpose(-1, -2)
+    step = graphed(lambda x: N().eig_sym(x, check_finite=False), a)
+    b = torch.randn(4096, 3, 3, device=dev, generator=g)
+    b = b + b.transpose(-1, -2)
+    assert torch.equal(step(b), N().eig_sym(b, check_finite=False))
+    with pytest.raises(Exception):
+        graphed(lambda x: N().eig_sym(x), a)        # the host read inside a capture is an error
+    torch.cuda.synchronize()

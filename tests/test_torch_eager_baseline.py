@@ -54,3 +54,19 @@ def test_broadcast_and_channel_first_views():
     assert x.shape == (5, 6, 4)
     y = T.sym_solve(mat.expand(5, 6, 10).contiguous(), vec)
     assert torch.equal(x, y)
+
+
+def test_other_workload_baselines_match_the_oracle(oracle, golden_sym, golden_reduce, golden_batched):
+    from oracle import torch_eager as T
+    for dn in ('f32', 'f64'):
+        k = f'{dn}_M3_'
+        assert relerr(T.sym_invert(torch.from_numpy(golden_sym[k + 'mat'])).numpy(), golden_sym[k + 'invert']) <= TOL[dn]
+        a = golden_batched[f'{dn}_n8_a']
+        assert relerr(T.batch_inv(torch.from_numpy(a)).numpy(), golden_batched[f'{dn}_n8_inv']) <= TOL[dn]
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(100_003).astype(np.float32)
+    x[rng.random(x.size) < 0.01] = np.nan
+    xt = torch.from_numpy(x)
+    assert float(T.nanmax(xt)) == float(oracle.reduce('nanmax', x)) == float(np.nanmax(x))
+    assert abs(float(T.nansum(xt)) - float(np.nansum(x.astype(np.float64)))) <= 1e-6 * float(np.nansum(np.abs(x)))
+    assert np.isnan(x).any() and not torch.isnan(xt[~torch.isnan(xt)]).any()          # the input copy is what gets filled
