@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NFM_VERSION 1
+#define NFM_VERSION 2 /* 2: nfm_qr_eig_sym takes flags (NFM_EIG_*); nfm_reduce_median added */
 #define NFM_MAX_DIM 16 /* largest matrix order handled (3x3 .. 16x16 and below) */
 
 /* dtype codes */
@@ -206,6 +206,18 @@ int nfm_reduce_moments(int dtype, int64_t outer, int64_t red, int64_t inner, con
 #define NFM_STAT_UNBIASED 8
 int nfm_reduce_stat(int dtype, int stat, int out_dtype, int64_t outer, int64_t red, int64_t inner,
                     const void *x, void *workspace, size_t workspace_bytes, void *out, void *stream);
+
+/* Median of every row of a contiguous (rows, red) array, `median` `reduce.py:384-428` (which
+ * moves the reduced dims last and calls torch.median; the facade does the same move): the
+ * LOWER median (rank (count - 1) / 2), by radix selection on order-preserving integer keys.
+ * omitnan = 0: a NaN in a row makes its median NaN (idx: the first NaN) -- what the reference
+ * computes; omitnan = 1: the median of the non-NaN elements (all NaN: NaN, idx 0) -- what its
+ * docstring promises (quirk Q14).  val: (rows) of `dtype`; idx: (rows) int64 or NULL = the first
+ * position holding the median value.  Rows of more than 1024 elements need a workspace of
+ * nfm_reduce_median_workspace_bytes(rows, red) bytes (0 for shorter rows) and rows <= 65535. */
+size_t nfm_reduce_median_workspace_bytes(int64_t rows, int64_t red);
+int nfm_reduce_median(int dtype, int omitnan, int64_t rows, int64_t red, const void *x, void *workspace,
+                      size_t workspace_bytes, void *val, void *idx, void *stream);
 
 /* ------------------------------------------------------------------- qr ---- */
 /* Real dtypes.  Multi-output routines write ONE packed, contiguous output record per

@@ -1,0 +1,470 @@
+// nfm_reduce_median.hip -- median of every row of a contiguous (rows, red) array by radix
+// selection: `median` of the reference (`reduce.py:384-428`, which defers to torch.median after
+// moving the reduced dims last -- the facade does the same move).
+//
+// Semantics (torch.median / torch.nanmedian): the LOWER median, i.e. the element of rank
+// (count - 1) / 2 in ascending order; omitnan = 0: any NaN in a row makes its median NaN (index:
+// the first NaN); omitnan = 1: the median of the non-NaN elements (all NaN: NaN, index 0).
+// Index: the first position that holds the median value (bit for bit: -0.0 sorts before +0.0).
+//
+// A float is mapped to an unsigned key that sorts like the float (sign bit flipped for positives,
+// all bits flipped for negatives; NaN -> the largest key, so NaNs sort last and are never selected
+// when omitted), and the key of rank k is found digit by digit, 8 bits at a time from the top:
+// count the elements per digit value among those that match the digits chosen so far, keep the
+// digit whose cumulative count passes k.  4 passes for float32, 8 for float64, no data movement.
+//
+//   red <= 32:   8 / 16 / 32 lanes per row, one element per lane, ranks counted directly;
+//   red <= 1024: one WAVEFRONT per row, the row in registers (<= 16 keys per lane), a 256-bin LDS
+//                histogram per wavefront, ds_add for the counts, a 64-lane scan to pick the digit;
+//   longer rows: every pass streams the row once with 16-byte loads -- a grid of (chunks, rows)
+//                workgroups histograms into LDS and adds its 256 counts to the row's global
+//                histogram; a one-wavefront kernel per row picks the digit between passes.  A full
+//                reduction of 2^33 elements is 4 passes at the streaming rate.
+#include "nfm_reduce_common.hpp"
+
+namespace nfm {
+namespace med {
+
+template <typename T>
+struct Key;
+template <>
+struct Key<float> {
+    using U = uint32_t;
+    static constexpr int digits = 4;
+    static __device__ __forceinline__ U of(float x)
+    {
+        const U u = (U)__float_as_int(x);
+        if (x != x) return ~U(0);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    static __device__ __forceinline__ float back(U k)
+    {
+        const U u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+        return __int_as_float((int)u);
+    }
+};
+template <>
+struct Key<double> {
+    using U = uint64_t;
+    static constexpr int digits = 8;
+    static __device__ __forceinline__ U of(double x)
+    {
+        const U u = (U)__double_as_longlong(x);
+        if (x != x) return ~U(0);
+        return (u >> 63) ? ~u : (u | (U(1) << 63));
+    }
+    static __device__ __forceinline__ double back(U k)
+    {
+        const U u = (k >> 63) ? (k & ~(U(1) << 63)) : ~k;
+        return __longlong_as_double((long long)u);
+    }
+};
+
+__device__ __forceinline__ unsigned wave_excl_scan(unsigned v, unsigned &total)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned s = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(s, off, 64);
+        if (lane >= off) s += o;
+    }
+    total = __shfl(s, 63, 64);
+    return s - v;
+}
+
+// pick the digit whose cumulative count passes k: `cnt` = this lane's 4 consecutive bins
+// (4 * lane .. 4 * lane + 3); returns the digit and reduces k to the rank inside that digit
+__device__ __forceinline__ unsigned pick_digit(const unsigned (&cnt)[4], unsigned long long &k)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned tot;
+    const unsigned mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const unsigned before = wave_excl_scan(mine, tot);
+    const bool here = (unsigned long long)before <= k && k < (unsigned long long)before + mine;
+    const unsigned long long m = __ballot(here);
+    const int src = m ? __builtin_ctzll(m) : 63; // k < total always: exactly one lane
+    unsigned digit = 0;
+    unsigned long long kk = k;
+    if (lane == src) {
+        unsigned long long r = k - before;
+        unsigned d = 0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (d == (unsigned)b && r >= cnt[b]) {
+                r -= cnt[b];
+                d = b + 1;
+            }
+        digit = 4 * lane + d;
+        kk = r;
+    }
+    digit = __shfl(digit, src, 64);
+    const unsigned lo = __shfl((unsigned)kk, src, 64), hi = __shfl((unsigned)(kk >> 32), src, 64);
+    k = ((unsigned long long)hi << 32) | lo;
+    return digit;
+}
+
+// ---------------------------------------------------------------------------------------------
+// short rows: one wavefront per row
+// the part of a key above digit d (0 for the top digit: nothing chosen yet)
+template <typename U>
+__device__ __forceinline__ U above(U key, int d, int digits)
+{
+    return d + 1 < digits ? (U)(key >> (8 * (d + 1))) : U(0);
+}
+
+// E = keys per lane: rows of up to 64 * E elements
+template <typename T, int E>
+__global__ __launch_bounds__(256) void median_rows_kernel(const T *__restrict__ x, int64_t rows, int red, int omitnan,
+                                                          T *__restrict__ val, int64_t *__restrict__ idx)
+{
+    using K = Key<T>;
+    using U = typename K::U;
+    __shared__ unsigned hist_all[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned *hist = hist_all[w];
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= rows) return; // whole wavefronts leave: no barrier below is workgroup-wide
+    const T *p = x + row * red;
+    U key[E];
+    unsigned nan = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = lane + 64 * e;
+        const T v = j < red ? NFM_LDG(p + j) : T(0);
+        key[e] = K::of(v);
+        nan += (j < red && v != v) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nan += __shfl_xor(nan, off, 64);
+    const unsigned count = omitnan ? (unsigned)red - nan : (unsigned)red;
+    U chosen;
+    bool want_nan = false;
+    if ((!omitnan && nan > 0) || count == 0) {
+        chosen = ~U(0);
+        want_nan = true;
+    } else {
+        unsigned long long k = (count - 1) / 2;
+        U prefix = 0;
+#pragma unroll
+        for (int d = K::digits - 1; d >= 0; --d) {
+            const int shift = 8 * d;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int j = lane + 64 * e;
+                // elements that agree with the digits chosen so far (all of them in the first pass)
+                const bool in = j < red && above(key[e], d, K::digits) == prefix;
+                if (in) atomicAdd(&hist[(unsigned)(key[e] >> shift) & 255u], 1u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            unsigned cnt[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) cnt[b] = hist[4 * lane + b];
+            const unsigned digit = pick_digit(cnt, k);
+            prefix = (prefix << 8) | (U)digit;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        chosen = prefix;
+    }
+    // first position holding the chosen key (a NaN result: the first NaN; all-NaN with omitnan: 0)
+    int first = 0x7fffffff;
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) {
+        const int j = lane + 64 * e;
+        if (j < red && key[e] == chosen) first = j;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(first, off, 64);
+        first = o < first ? o : first;
+    }
+    if (lane == 0) {
+        val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
+        if (idx) idx[row] = first == 0x7fffffff ? 0 : first;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiny rows (red <= 32): G = 8 / 16 / 32 lanes per row, 64 / G rows per wavefront, one element per
+// lane; the rank of an element is counted directly -- #smaller + #equal at a lower position --
+// with one group broadcast per position, and the element of rank k is the median.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void median_tiny_kernel(const T *__restrict__ x, int64_t rows, int red, int omitnan,
+                                                          T *__restrict__ val, int64_t *__restrict__ idx)
+{
+    using K = Key<T>;
+    using U = typename K::U;
+    constexpr int RPW = 64 / G; // rows per wavefront
+    const int lane = threadIdx.x & 63, j = lane % G, gbase = lane - j;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+    const bool live = row < rows && j < red;
+    const T v = live ? NFM_LDG(x + row * red + j) : T(0);
+    const U key = live ? K::of(v) : ~U(0);
+    unsigned nan = (live && v != v) ? 1u : 0u;
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) nan += __shfl_xor(nan, off, 64);
+    const unsigned count = omitnan ? (unsigned)red - nan : (unsigned)red;
+    const bool want_nan = (!omitnan && nan > 0) || count == 0;
+    const unsigned k = count ? (count - 1) / 2 : 0;
+    unsigned rank = 0;
+    for (int t = 0; t < red; ++t) { // red is uniform; positions beyond it hold nothing
+        U kt;
+        if constexpr (sizeof(U) == 4) kt = (U)__shfl((unsigned)key, gbase + t, 64);
+        else {
+            const unsigned lo = __shfl((unsigned)key, gbase + t, 64), hi = __shfl((unsigned)(key >> 32), gbase + t, 64);
+            kt = ((U)hi << 32) | lo;
+        }
+        rank += (kt < key || (kt == key && t < j)) ? 1u : 0u;
+    }
+    // exactly one live lane of the row has rank k (NaN keys are the largest: never rank k when omitted)
+    const unsigned long long hit = __ballot(live && !want_nan && rank == k);
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+    const int src = (hit & gmask) ? __builtin_ctzll(hit & gmask) : gbase;
+    U chosen;
+    if constexpr (sizeof(U) == 4) chosen = (U)__shfl((unsigned)key, src, 64);
+    else {
+        const unsigned lo = __shfl((unsigned)key, src, 64), hi = __shfl((unsigned)(key >> 32), src, 64);
+        chosen = ((U)hi << 32) | lo;
+    }
+    if (want_nan) chosen = ~U(0);
+    const unsigned long long same = __ballot(live && key == chosen) & gmask;
+    if (j == 0 && row < rows) {
+        val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
+        if (idx) idx[row] = same ? (int64_t)(__builtin_ctzll(same) - gbase) : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// long rows: per-row state in the workspace
+struct RowState {
+    unsigned long long prefix; // digits chosen so far
+    unsigned long long k;      // rank still to resolve inside the prefix
+    unsigned long long nan;    // NaNs in the row (counted by the first pass)
+    unsigned long long first;  // first position of the result
+    int want_nan;              // the result is NaN
+    int pad;
+};
+static_assert(sizeof(RowState) == 40, "workspace layout");
+
+template <typename T>
+__global__ __launch_bounds__(256) void median_hist_kernel(const T *__restrict__ x, int64_t red, int64_t chunk, int d,
+                                                          const RowState *__restrict__ st, unsigned *__restrict__ ghist,
+                                                          unsigned long long *__restrict__ gnan)
+{
+    using K = Key<T>;
+    using U = typename K::U;
+    using V = typename VecOf<T>::gtype;
+    constexpr int NV = VecOf<T>::N;
+    __shared__ unsigned hist[256];
+    __shared__ unsigned nan_s;
+    const int64_t row = blockIdx.y;
+    if (d != K::digits - 1 && st[row].want_nan) return;
+    hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nan_s = 0;
+    __syncthreads();
+    const bool first_pass = d == K::digits - 1;
+    const U prefix = first_pass ? U(0) : (U)st[row].prefix;
+    const int shift = 8 * d;
+    const T *p = x + row * red;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < red ? lo + chunk : red;
+    unsigned nan = 0;
+    auto take = [&](T v) {
+        const U key = K::of(v);
+        if (first_pass) nan += (v != v) ? 1u : 0u;
+        if (above(key, d, K::digits) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+    };
+    // 16-byte loads over the aligned middle of the chunk, elements at its ragged ends
+    int64_t j = lo + threadIdx.x;
+    const int64_t mis = (int64_t)((reinterpret_cast<uintptr_t>(p + lo) / sizeof(T)) % NV);
+    const int64_t head = mis ? (NV - mis < hi - lo ? NV - mis : hi - lo) : 0;
+    if (j < lo + head) take(NFM_LDG(p + j));
+    const int64_t body0 = lo + head, nvec = (hi - body0) / NV;
+    for (int64_t q = threadIdx.x; q < nvec; q += 256) {
+        const V v = NFM_LDG(reinterpret_cast<const V *>(p + body0) + q);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) take(v[c]);
+    }
+    j = body0 + nvec * NV + threadIdx.x;
+    if (j < hi) take(NFM_LDG(p + j));
+    if (first_pass) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nan += __shfl_xor(nan, off, 64);
+        if ((threadIdx.x & 63) == 0 && nan) atomicAdd(&nan_s, nan);
+    }
+    __syncthreads();
+    const unsigned c = hist[threadIdx.x];
+    if (c) atomicAdd(&ghist[row * 256 + threadIdx.x], c);
+    if (first_pass && threadIdx.x == 0 && nan_s) atomicAdd(&gnan[row], (unsigned long long)nan_s);
+}
+
+// one wavefront per row: choose the digit of this pass, clear the histogram for the next one
+template <typename T>
+__global__ __launch_bounds__(64) void median_pick_kernel(int64_t red, int d, int omitnan, RowState *__restrict__ st,
+                                                         unsigned *__restrict__ ghist,
+                                                         unsigned long long *__restrict__ gnan, T *__restrict__ val)
+{
+    using K = Key<T>;
+    using U = typename K::U;
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    RowState s = st[row];
+    if (d == K::digits - 1) {
+        s.prefix = 0;
+        s.nan = gnan[row];
+        const unsigned long long count = omitnan ? (unsigned long long)red - s.nan : (unsigned long long)red;
+        s.want_nan = ((!omitnan && s.nan > 0) || count == 0) ? 1 : 0;
+        s.k = count ? (count - 1) / 2 : 0;
+        s.first = red; // "not found yet" for the index pass
+    }
+    if (!s.want_nan) {
+        unsigned cnt[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cnt[b] = ghist[row * 256 + 4 * lane + b];
+        unsigned long long k = s.k;
+        const unsigned digit = pick_digit(cnt, k);
+        s.k = k;
+        s.prefix = (s.prefix << 8) | digit;
+    } else {
+        s.prefix = ~0ull;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ghist[row * 256 + 4 * lane + b] = 0;
+    if (lane == 0) {
+        st[row] = s;
+        if (d == 0) val[row] = s.want_nan ? (T)__builtin_nanf("") : K::back((U)s.prefix);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void median_index_kernel(const T *__restrict__ x, int64_t red, int64_t chunk,
+                                                           RowState *__restrict__ st)
+{
+    using K = Key<T>;
+    using U = typename K::U;
+    const int64_t row = blockIdx.y;
+    const U chosen = st[row].want_nan ? ~U(0) : (U)st[row].prefix;
+    const T *p = x + row * red;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < red ? lo + chunk : red;
+    unsigned long long first = ~0ull;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256)
+        if (K::of(NFM_LDG(p + j)) == chosen) {
+            first = (unsigned long long)j;
+            break; // positions grow with j: the first hit of this thread is its smallest
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo32 = __shfl_xor((unsigned)first, off, 64), hi32 = __shfl_xor((unsigned)(first >> 32), off, 64);
+        const unsigned long long o = ((unsigned long long)hi32 << 32) | lo32;
+        first = o < first ? o : first;
+    }
+    if ((threadIdx.x & 63) == 0 && first != ~0ull) atomicMin(&st[row].first, first);
+}
+
+__global__ void median_store_index_kernel(int64_t rows, int64_t red, const RowState *__restrict__ st,
+                                          int64_t *__restrict__ idx)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < rows) idx[row] = st[row].first >= (unsigned long long)red ? 0 : (int64_t)st[row].first;
+}
+
+constexpr int kShortMax = 1024;
+
+static int64_t chunk_of(int64_t rows, int64_t red)
+{
+    // ~2048 workgroups in flight, chunks of at least 16 Ki elements, a multiple of 1024
+    int64_t per_row = (2048 + rows - 1) / rows;
+    if (per_row < 1) per_row = 1;
+    int64_t chunk = (red + per_row - 1) / per_row;
+    if (chunk < 16384) chunk = 16384;
+    return ((chunk + 1023) / 1024) * 1024;
+}
+
+template <typename T>
+static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, size_t ws_bytes, void *val, void *idx,
+               void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (red <= 32) {
+        const int G = red <= 8 ? 8 : (red <= 16 ? 16 : 32);
+        const int64_t nblk = (rows + 4 * (64 / G) - 1) / (4 * (64 / G));
+        if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+#define NFM_MED_TINY(Gv)                                                                                              \
+    hipLaunchKernelGGL((median_tiny_kernel<T, Gv>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const T *>(x), \
+                       rows, (int)red, omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx))
+        if (G == 8) NFM_MED_TINY(8);
+        else if (G == 16) NFM_MED_TINY(16);
+        else NFM_MED_TINY(32);
+#undef NFM_MED_TINY
+        return launch_status();
+    }
+    if (red <= kShortMax) {
+        const int64_t nblk = (rows + 3) / 4;
+        if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+#define NFM_MED_ROWS(Ev)                                                                                              \
+    hipLaunchKernelGGL((median_rows_kernel<T, Ev>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const T *>(x), \
+                       rows, (int)red, omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx))
+        if (red <= 64) NFM_MED_ROWS(1);
+        else if (red <= 128) NFM_MED_ROWS(2);
+        else if (red <= 256) NFM_MED_ROWS(4);
+        else if (red <= 512) NFM_MED_ROWS(8);
+        else NFM_MED_ROWS(16);
+#undef NFM_MED_ROWS
+        return launch_status();
+    }
+    if (rows > 65535) return NFM_ESIZE; // grid.y; the facade splits (long rows are few)
+    const size_t need = (size_t)rows * (sizeof(RowState) + 256 * sizeof(unsigned) + sizeof(unsigned long long));
+    if (ws == nullptr || ws_bytes < need) return NFM_EINVAL;
+    RowState *st = static_cast<RowState *>(ws);
+    unsigned long long *gnan = reinterpret_cast<unsigned long long *>(st + rows);
+    unsigned *ghist = reinterpret_cast<unsigned *>(gnan + rows);
+    hipError_t e = hipMemsetAsync(ws, 0, need, s);
+    if (e != hipSuccess) return (int)e;
+    const int64_t chunk = chunk_of(rows, red);
+    const int64_t nch = (red + chunk - 1) / chunk;
+    if (nch > 0x7fffffffLL) return NFM_ESIZE;
+    for (int d = Key<T>::digits - 1; d >= 0; --d) {
+        hipLaunchKernelGGL((median_hist_kernel<T>), dim3((unsigned)nch, (unsigned)rows), dim3(256), 0, s,
+                           static_cast<const T *>(x), red, chunk, d, st, ghist, gnan);
+        hipLaunchKernelGGL((median_pick_kernel<T>), dim3((unsigned)rows), dim3(64), 0, s, red, d, omitnan, st, ghist, gnan,
+                           static_cast<T *>(val));
+    }
+    if (idx) {
+        hipLaunchKernelGGL((median_index_kernel<T>), dim3((unsigned)nch, (unsigned)rows), dim3(256), 0, s,
+                           static_cast<const T *>(x), red, chunk, st);
+        hipLaunchKernelGGL(median_store_index_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, rows, red, st,
+                           static_cast<int64_t *>(idx));
+    }
+    return launch_status();
+}
+
+} // namespace med
+} // namespace nfm
+
+using namespace nfm;
+
+extern "C" {
+
+size_t nfm_reduce_median_workspace_bytes(int64_t rows, int64_t red)
+{
+    if (rows <= 0 || red <= med::kShortMax) return 0;
+    return (size_t)rows * (sizeof(med::RowState) + 256 * sizeof(unsigned) + sizeof(unsigned long long));
+}
+
+int nfm_reduce_median(int dtype, int omitnan, int64_t rows, int64_t red, const void *x, void *workspace,
+                      size_t workspace_bytes, void *val, void *idx, void *stream)
+{
+    if (dtype != NFM_F32 && dtype != NFM_F64) return NFM_EDTYPE;
+    if (rows < 0 || red < 0) return NFM_EINVAL;
+    if (rows == 0) return NFM_OK;
+    if (red == 0 || x == nullptr || val == nullptr) return NFM_EINVAL;
+    return dtype == NFM_F32 ? med::run<float>(omitnan ? 1 : 0, rows, red, x, workspace, workspace_bytes, val, idx, stream)
+                            : med::run<double>(omitnan ? 1 : 0, rows, red, x, workspace, workspace_bytes, val, idx, stream);
+}
+
+} // extern "C"

@@ -11,8 +11,8 @@ NaN-aware reductions on MI355X -- drop-in for `nitorch_fastmath.reduce`
 The reference makes several full passes over memory per call (clone, isnan,
 masked_fill, reduce: `reduce.py:502-510`) and half of it raises on current PyTorch
 (SURVEY quirks Q10-Q13).  Here every reduction is one streaming HIP kernel (NaN ->
-identity by select, 64-lane wavefront shuffle reduce, double accumulation), and the
-functions that raise upstream implement their documented semantics.
+identity by select, 64-lane wavefront shuffle reduce, double accumulation), `median` a radix
+selection, and the functions that raise upstream implement their documented semantics.
 
 `inplace=True` only ever meant "the input MAY be modified" (`reduce.py:72-74`); the reference
 uses that permission (its `nansum` zeroes, its `nanmax` / `nanmin` write -inf / +inf over, the
@@ -279,37 +279,58 @@ def nanmin(input, dim=None, keepdim=False, inplace=False, return_indices=False, 
 
 def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_indices=False, out=None):
     r"""Multi-dimensional median (`reduce.py:384-428`): the lower of the two middle values for an
-    even count, and the index of the element that holds it.
+    even count, and the index of the first element that holds it.
 
-    `omitnan=False` (the default) is what the reference computes: `torch.median`, i.e. a NaN in a
-    slice makes that slice's median NaN -- its docstring says "always omits NaNs" but its code never
-    does (SURVEY quirk Q14; pinned by tests/test_gpu_reduce.py::test_median_semantics).
+    `omitnan=False` (the default) is what the reference computes: it calls `torch.median`, so a NaN
+    in a slice makes that slice's median NaN -- its docstring says "always omits NaNs" but its code
+    never does (SURVEY quirk Q14; pinned by tests/test_gpu_reduce.py::test_median_semantics).
     `omitnan=True` is the documented intent: the median of the non-NaN values (all-NaN -> NaN).
 
-    Not a streaming reduction: a selection.  It runs torch's selection kernels on the device with
-    the reference's multi-dim handling and index layout (`(..., len(dim))`, last axis dropped for a
-    scalar `dim`); it is the one function of this module without a kernel in libnfm_hip.so.
+    One radix-selection kernel (`nfm_reduce_median`): no sort, no copy of the data beyond the move
+    of the reduced dims to the end that the reference does too (`reduce.py:112-113`).
     """
     input = torch.as_tensor(input)
-    require_gpu(input)
-    fn = torch.nanmedian if omitnan else torch.median
-    if dim is None:
-        return _deliver(fn(input), out)
-    scalar_dim = not isinstance(dim, (list, tuple, range))
+    dev = require_gpu(input)
+    grad = _needs_grad(input)
+    if grad and out is not None:
+        raise RuntimeError('out= is not supported for tensors that require grad')
+    code = dtype_code(input.dtype)
     nd = input.dim()
-    dims = [d if d >= 0 else nd + d for d in ensure_list(dim)]
+    scalar_dim = dim is not None and not isinstance(dim, (list, tuple, range))
+    dims = list(range(nd)) if dim is None else [d if d >= 0 else nd + d for d in ensure_list(dim)]
+    if len(set(dims)) != len(dims) or any(d < 0 or d >= nd for d in dims):
+        raise IndexError(f'invalid reduction dims {dim} for a {nd}-d tensor')
     kept = [d for d in range(nd) if d not in dims]
     redshape = [input.shape[d] for d in dims]
-    x = input.permute(kept + dims).reshape([input.shape[d] for d in kept] + [-1])
-    val, idx = fn(x, dim=-1)
-    if keepdim:
-        keptshape = [1 if d in dims else s for d, s in enumerate(input.shape)]
-        val, idx = val.reshape(keptshape), idx.reshape(keptshape)
+    subshape = [input.shape[d] for d in kept]
+    red, rows = _prod(redshape), _prod(subshape)
+    if red == 0:
+        raise IndexError('cannot take the median over an empty dimension')
+    xg = input.permute(kept + dims).reshape(rows, red)       # differentiable view / copy of the rows
+    x = xg.detach()
+    if not x.is_contiguous():
+        x = x.contiguous()
+    val = torch.empty(rows, dtype=input.dtype, device=dev)
+    want_idx = return_indices and dim is not None
+    idx = torch.empty(rows, dtype=torch.long, device=dev) if (want_idx or grad) else None
+    L = _lib.lib()
+    step = rows if red <= 1024 else 65535          # long rows: grid.y bound of the histogram passes
+    for lo in range(0, rows, builtins.max(step, 1)):
+        hi = builtins.min(rows, lo + step)
+        ws, wsn = _workspace(dev, L.nfm_reduce_median_workspace_bytes(hi - lo, red))
+        with torch.cuda.device(dev):
+            _lib.check(L.nfm_reduce_median(code, int(bool(omitnan)), hi - lo, red, x[lo:hi].data_ptr(),
+                                           ws.data_ptr() if ws is not None else None, wsn, val[lo:hi].data_ptr(),
+                                           idx[lo:hi].data_ptr() if idx is not None else None, stream_ptr(dev)))
+    if grad:      # the gradient goes to the selected element: pick it out of the differentiable rows
+        val = xg.gather(1, idx[:, None])[:, 0]
+    shape = [1 if d in dims else s for d, s in enumerate(input.shape)] if keepdim else subshape
+    val = val.reshape(shape)
     out_val, out_ind = ensure_list(out, 2, default=None) if out is not None else (None, None)
     val = _deliver(val, out_val)
-    if not return_indices:
+    if not want_idx:
         return val
-    sub = torch.movedim(ind2sub(idx, redshape), 0, -1)
+    sub = torch.movedim(ind2sub(idx.reshape(shape), redshape), 0, -1)
     if scalar_dim:
         sub = sub[..., 0]
     return val, _deliver(sub, out_ind)

@@ -11,7 +11,7 @@ import numpy as np
 
 __all__ = ['build', 'lib', 'sym_solve', 'sym_matvec', 'sym_invert', 'sym_det', 'sym_to_full',
            'sym_outer', 'sym_matmul', 'batch_inv', 'batch_det', 'batch_matvec', 'reduce', 'givens', 'givens_apply', 'householder',
-           'householder_apply', 'hessenberg', 'hessenberg_sym', 'qr_hessenberg', 'rq_hessenberg', 'eig_sym',
+           'householder_apply', 'hessenberg', 'hessenberg_sym', 'qr_hessenberg', 'rq_hessenberg', 'eig_sym', 'median',
            'set_num_threads']
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -318,3 +318,33 @@ def eig_sym(a, compute_u=False, upper=True, max_iter=1024, tol=1e-32, return_swe
     _chk(lib().nfm_oracle_qr_eig_sym(_dt(a), N, ctypes.c_int64(_nb(a, 2)), int(upper), int(compute_u), int(max_iter),
                                      ctypes.c_double(tol), _p(a), _p(vals), _p(vecs)))
     return (vals, vecs) if compute_u else vals
+
+
+def median(x, axis=None, omitnan=False):
+    """`median` (`reduce.py:384-428` = torch.median after moving the reduced dims last): the LOWER
+    median (rank (count - 1) // 2) and the first position holding it (signed zeros: -0.0 sorts
+    before +0.0, they stay equal as numbers); a NaN propagates unless omitnan (the docstring's
+    intent, quirk Q14).  Plain numpy sort: small cases only.
+    Returns (values, flat indices into the reduced dims)."""
+    x = np.asarray(x)
+    if axis is None:
+        rows = x.reshape(1, -1)
+        shape = ()
+    else:
+        axes = tuple(a % x.ndim for a in (axis if isinstance(axis, (tuple, list)) else (axis,)))
+        kept = [d for d in range(x.ndim) if d not in axes]
+        rows = np.transpose(x, kept + list(axes)).reshape(int(np.prod([x.shape[d] for d in kept], dtype=np.int64)), -1)
+        shape = tuple(x.shape[d] for d in kept)
+    vals = np.empty(len(rows), x.dtype)
+    idx = np.zeros(len(rows), np.int64)
+    for r, row in enumerate(rows):
+        nan = np.isnan(row)
+        if (nan.any() and not omitnan) or nan.all():
+            vals[r] = np.nan
+            idx[r] = int(np.argmax(nan)) if nan.any() and not omitnan else 0
+            continue
+        v = row[~nan]
+        v = v[np.lexsort((~np.signbit(v), v))]          # ascending, -0.0 before +0.0 (equal as numbers)
+        vals[r] = v[(len(v) - 1) // 2]
+        idx[r] = int(np.argmax((row == vals[r]) & (np.signbit(row) == np.signbit(vals[r]))))
+    return vals.reshape(shape), idx.reshape(shape)

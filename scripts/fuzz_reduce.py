@@ -61,6 +61,15 @@ def check(x, xd, what):
         assert np.abs(r[ok] - ev[ok]).max(initial=0) <= 1e-11 * big * big, (what, 'nanvar')
     s = R.std(xd, dim=1).cpu().numpy()
     assert np.array_equal(np.isnan(s), anyn | (x.shape[1] < 2)), (what, 'std nan')
+    # median / nan-omitting median: the radix selection against a sort (torch on the CPU: lower median)
+    xt = torch.from_numpy(x)
+    for omit, fn in ((False, torch.median), (True, torch.nanmedian)):
+        v, i = R.median(xd, dim=1, omitnan=omit, return_indices=True)
+        v, i = v.cpu().numpy(), i.cpu().numpy()
+        ev = fn(xt, dim=1).values.numpy()
+        assert np.array_equal(np.isnan(v), np.isnan(ev)) and np.array_equal(v[~np.isnan(v)], ev[~np.isnan(ev)]), (what, 'median', omit)
+        picked = np.take_along_axis(x, i[:, None, :], axis=1)[:, 0, :]
+        assert np.array_equal(np.isnan(picked), np.isnan(v)) and np.array_equal(picked[~np.isnan(v)], v[~np.isnan(v)]), (what, 'median idx')
 
 
 t0 = time.time()

@@ -309,3 +309,22 @@ def test_sym_to_full_outer_matmul_backward(dev, M):
         if M > 1:       # (M == 1: a 1-vector is read as compact 1x1, same thing)
             assert torch.allclose(dd.grad.cpu(), dc.grad, rtol=1e-10, atol=1e-11), (M, d)
         assert torch.allclose(jd.grad.cpu(), jc.grad, rtol=1e-10, atol=1e-11), (M, d)
+
+
+def test_median_backward(dev):
+    """the gradient of a median goes to the element that was picked (what torch.median's own
+    backward does on the reference's path)"""
+    import nitorch_fastmath_amd as N_
+    torch.manual_seed(4)
+    x = torch.randn(6, 9, 5, device=dev, dtype=torch.float64, requires_grad=True)
+    v, i = N_.reduce.median(x, dim=1, return_indices=True)
+    v.sum().backward()
+    ref = torch.zeros_like(x)
+    ref.scatter_(1, i.unsqueeze(1), 1.0)
+    assert torch.equal(x.grad, ref) and x.grad.sum() == 30
+    xr = x.detach().clone().requires_grad_(True)
+    torch.median(xr, dim=1).values.sum().backward()
+    assert torch.equal(x.grad, xr.grad)                     # no duplicates in a random draw: same element
+    y = torch.randn(1000, device=dev, requires_grad=True)
+    N_.reduce.median(y).backward()
+    assert y.grad.sum() == 1 and y.grad[y.detach().argsort()[499]] == 1

@@ -404,14 +404,18 @@ def test_inplace_never_modifies_the_input(dev):
 def test_median_semantics(dev):
     """quirk Q14: the reference's `median` docstring says "always omits NaNs", its code calls
     `torch.median`, which propagates them.  Here `omitnan=False` (default) = the reference's actual
-    result, `omitnan=True` = the documented intent; index layout as for max / min."""
+    result, `omitnan=True` = the documented intent; index layout as for max / min; the index is the
+    FIRST position holding the median value (torch picks the position a stable sort would put at the
+    median's rank: the same value, possibly another of its duplicates)."""
     x = torch.tensor([[3., float('nan'), 1., 2., 5.], [4., 1., 3., 2., 0.], [float('nan')] * 5], device=dev)
     m = R().median(x, dim=1)
     assert torch.isnan(m[0]) and m[1] == 2 and torch.isnan(m[2])                   # = torch.median
-    assert torch.equal(torch.isnan(m), torch.isnan(torch.median(x, dim=1).values))
+    assert torch.equal(torch.isnan(m), torch.isnan(torch.median(x.cpu(), dim=1).values.to(dev)))
     mo, io = R().median(x, dim=1, omitnan=True, return_indices=True)
     assert mo[0] == 2 and mo[1] == 2 and torch.isnan(mo[2])                        # lower median of {1,2,3,5}
-    assert io[0] == 3 and io[1] == 3 and io.dtype == torch.long
+    assert io[0] == 3 and io[1] == 3 and io[2] == 0 and io.dtype == torch.long
+    mn, i_n = R().median(x, dim=1, return_indices=True)
+    assert i_n[0] == 1 and i_n[2] == 0                                             # the first NaN
     assert R().median(x[1]) == 2 and torch.isnan(R().median(x))
     assert R().median(x, omitnan=True) == 2                                        # {0,1,1,2,2,3,3,4,5} -> 2
     y = torch.arange(24., device=dev).reshape(2, 3, 4)
@@ -419,3 +423,60 @@ def test_median_semantics(dev):
     assert v.tolist() == [3., 7., 11.] and i.shape == (3, 2) and i[0].tolist() == [0, 3]
     vk = R().median(y, dim=(0, 2), keepdim=True)
     assert vk.shape == (1, 3, 1)
+    with pytest.raises(IndexError):
+        R().median(torch.zeros(3, 0, device=dev), dim=1)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('red', [1, 2, 3, 27, 63, 64, 65, 127, 128, 129, 500, 1023, 1024, 1025, 4097, 70001])
+def test_median_vs_oracle_and_torch(dev, oracle, dn, red):
+    """every row-length regime of the radix selection (1 / 2 / 4 / 8 / 16 keys per lane, the
+    multi-pass histogram form beyond 1024), NaNs, signed zeros, infinities, duplicates; values equal
+    to numpy's sort and to torch.median / nanmedian on the CPU, bit for bit"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(red)
+    rows = 37 if red <= 1025 else 5
+    x = rng.standard_normal((rows, red)).astype(dtype)
+    x[0] = np.round(x[0] * 2) / 2                      # many duplicates
+    if red > 2:
+        x[1, ::3] = np.nan
+        x[2, 0], x[2, -1], x[2, red // 2] = np.inf, -np.inf, -0.0
+        x[3] = np.nan                                   # all NaN
+        x[4, 1] = np.nan
+    xd = t(x, dev)
+    for omit in (False, True):
+        v, i = R().median(xd, dim=1, omitnan=omit, return_indices=True)
+        rv, ri = oracle.median(x, 1, omitnan=omit)
+        v, i = v.cpu().numpy(), i.cpu().numpy()
+        assert np.array_equal(np.isnan(v), np.isnan(rv)) and np.array_equal(v[~np.isnan(v)], rv[~np.isnan(rv)]), omit
+        assert np.array_equal(i, ri), omit
+        tv = (torch.nanmedian if omit else torch.median)(torch.from_numpy(x), dim=1).values.numpy()
+        assert np.array_equal(np.isnan(v), np.isnan(tv)) and np.array_equal(v[~np.isnan(v)], tv[~np.isnan(tv)])
+        ok = ~np.isnan(v)
+        assert np.array_equal(x[np.arange(rows)[ok], i[ok]].view(np.uint8), v[ok].view(np.uint8))   # the index holds the value, bit for bit
+    # columns (reduced dim first) and the whole tensor
+    v0 = R().median(xd.t().contiguous(), dim=0, omitnan=True).cpu().numpy()
+    assert np.array_equal(np.nan_to_num(v0, nan=7.0), np.nan_to_num(oracle.median(x, 1, omitnan=True)[0], nan=7.0))
+    flat = R().median(xd, omitnan=True)
+    assert float(flat) == float(oracle.median(x.reshape(-1), None, omitnan=True)[0])
+
+
+def test_median_large(dev):
+    """2^27 elements in one row (the dim=None form of a volume): 4 streaming passes; against a full
+    device sort (torch.nanmedian on the device returned another element for this input), plus a 3-D
+    field reduced over its spatial dims"""
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(1 << 27, device=dev, generator=g)
+    x[::1001] = float('nan')
+    got = R().median(x, omitnan=True)
+    valid = x[~torch.isnan(x)]
+    truth = torch.sort(valid).values[(valid.numel() - 1) // 2]          # the lower median by a full sort
+    assert got == truth, (float(got), float(truth), float(torch.nanmedian(x)))
+    assert torch.isnan(R().median(x))
+    y = x[: (1 << 26) + 12345].clone().nan_to_num_(0.25)                   # odd length, no NaN, one value repeated
+    assert R().median(y) == torch.sort(y).values[(y.numel() - 1) // 2]
+    f = torch.randn(3, 8, 200, 200, device=dev, generator=g)
+    v, i = R().median(f, dim=(2, 3), return_indices=True)
+    ref = torch.median(f.reshape(3, 8, -1), dim=-1).values
+    assert torch.equal(v, ref) and i.shape == (3, 8, 2)
+    assert torch.equal(f[torch.arange(3)[:, None], torch.arange(8)[None], i[..., 0], i[..., 1]], v)
