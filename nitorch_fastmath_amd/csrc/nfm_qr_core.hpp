@@ -152,7 +152,7 @@ __device__ __forceinline__ void rot1(T &a0, T &a1, T c, T s)
 
 // householder_ :55-69 on x[0..m), reflecting onto component `basis` (compile-time or not;
 // the element is picked by a select so that registers are never indexed dynamically)
-template <typename T, int NT>
+template <typename T, int NT, bool FAST = false>
 __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis)
 {
 #pragma clang fp contract(off)
@@ -167,6 +167,28 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
 #pragma unroll
     for (int i = 0; i < Dim<NT>::MAX; ++i)
         if (i < m) ss += x[i] * x[i];
+    if constexpr (FAST) {
+        // eig_sym's fast arithmetic (policy above): |x| = ss * rsqrt(ss), u = x / |x| = x * rsqrt(ss2);
+        // sums of squares outside the safe range (zero vectors, denormals, overflow) take the IEEE form
+        const bool ok1 = ss > FastRange<T>::lo && ss < FastRange<T>::hi;
+        rho *= ok1 ? ss * rsq_nr(ss) : sqrt_(ss);
+#pragma unroll
+        for (int i = 0; i < Dim<NT>::MAX; ++i)
+            if (i < m) x[i] = (i == basis) ? x[i] - rho : x[i];
+        T ss2 = T(0);
+#pragma unroll
+        for (int i = 0; i < Dim<NT>::MAX; ++i)
+            if (i < m) ss2 += x[i] * x[i];
+        const bool ok2 = ss2 > FastRange<T>::lo && ss2 < FastRange<T>::hi;
+        const T inv = ok2 ? rsq_nr(ss2) : T(1) / sqrt_(ss2);
+#pragma unroll
+        for (int i = 0; i < Dim<NT>::MAX; ++i)
+            if (i < m) {
+                const T v = x[i] * inv;
+                x[i] = finite_(v) ? v : T(0);
+            }
+        return rho;
+    }
     rho *= sqrt_(ss);
 #pragma unroll
     for (int i = 0; i < Dim<NT>::MAX; ++i)
@@ -239,7 +261,7 @@ __device__ __forceinline__ void hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], 
 // hessenberg_sym_lower_ :296-323 on a matrix whose LOWER triangle holds the data (the
 // caller mirrors the requested triangle on load, which is what the reference's transposed
 // view does for upper=True).  Output: symmetric tridiagonal, both halves filled.
-template <typename T, int NT, bool WITH_U>
+template <typename T, int NT, bool WITH_U, bool FAST = false>
 __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n,
                                                 T (&up)[Dim<NT>::MAX][Dim<NT>::MAX])
 {
@@ -253,7 +275,7 @@ __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MA
 #pragma unroll
             for (int r = 0; r < MX; ++r)
                 if (r < m) u[r] = a[o + r][k];
-            const T alpha = householder1<T, NT>(u, m, 0);
+            const T alpha = householder1<T, NT, FAST>(u, m, 0);
             if (WITH_U) {
 #pragma unroll
                 for (int r = 0; r < MX; ++r)
@@ -527,7 +549,7 @@ __device__ __forceinline__ void eig_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (
 {
     constexpr int MX = Dim<NT>::MAX;
     T up[MX][MX];
-    hessenberg_sym1<T, NT, WITH_U>(a, n, up);
+    hessenberg_sym1<T, NT, WITH_U, FAST>(a, n, up);
     qr_explicit1<T, NT, WITH_U, FAST>(a, u, n, max_iter, tol);
     if (WITH_U) {
         // householder_apply_(u, q, side='left', inverse=True): reflectors in reverse order
