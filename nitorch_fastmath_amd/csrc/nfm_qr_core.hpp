@@ -106,20 +106,25 @@ struct FastRange<double> {
 template <typename T>
 __device__ __forceinline__ void givens1(T x, T y, T &c, T &s);
 
-// sweep form of the same rotation (policy above)
+// sweep form of the same rotation (policy above).  The fast values are computed unconditionally;
+// only if SOME lane of the wavefront is outside the safe range (a uniform vote: no exec-mask
+// juggling on the common path) the IEEE form runs as well and those lanes take its result.
 template <typename T>
 __device__ __forceinline__ void givens_fast1(T x, T y, T &c, T &s)
 {
     const T r2 = fma_t(x, x, y * y);
-    if (__builtin_expect(!(r2 > FastRange<T>::lo && r2 < FastRange<T>::hi), 0)) {
-        givens1<T>(x, y, c, s);
-        return;
-    }
+    const bool ok = r2 > FastRange<T>::lo && r2 < FastRange<T>::hi;
     const T inv = rsq_nr(r2);
     // an axis-aligned pair is an exact rotation in the reference (x / |x| = +-1): keep it exact, so
     // that diagonal / already deflated input comes back bit for bit
     c = (y == T(0)) ? copysign_t(T(1), x) : x * inv;
     s = (x == T(0)) ? -copysign_t(T(1), y) : -(y * inv);
+    if (__builtin_expect(__any(!ok), 0)) {
+        T c2, s2;
+        givens1<T>(x, y, c2, s2);
+        c = ok ? c : c2;
+        s = ok ? s : s2;
+    }
 }
 
 template <typename T>
@@ -170,8 +175,14 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
     if constexpr (FAST) {
         // eig_sym's fast arithmetic (policy above): |x| = ss * rsqrt(ss), u = x / |x| = x * rsqrt(ss2);
         // sums of squares outside the safe range (zero vectors, denormals, overflow) take the IEEE form
+        // (uniform votes, as in givens_fast1)
         const bool ok1 = ss > FastRange<T>::lo && ss < FastRange<T>::hi;
-        rho *= ok1 ? ss * rsq_nr(ss) : sqrt_(ss);
+        T nrm1 = ss * rsq_nr(ss);
+        if (__builtin_expect(__any(!ok1), 0)) {
+            const T e = sqrt_(ss);
+            nrm1 = ok1 ? nrm1 : e;
+        }
+        rho *= nrm1;
 #pragma unroll
         for (int i = 0; i < Dim<NT>::MAX; ++i)
             if (i < m) x[i] = (i == basis) ? x[i] - rho : x[i];
@@ -180,7 +191,11 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
         for (int i = 0; i < Dim<NT>::MAX; ++i)
             if (i < m) ss2 += x[i] * x[i];
         const bool ok2 = ss2 > FastRange<T>::lo && ss2 < FastRange<T>::hi;
-        const T inv = ok2 ? rsq_nr(ss2) : T(1) / sqrt_(ss2);
+        T inv = rsq_nr(ss2);
+        if (__builtin_expect(__any(!ok2), 0)) {
+            const T e = T(1) / sqrt_(ss2);
+            inv = ok2 ? inv : e;
+        }
 #pragma unroll
         for (int i = 0; i < Dim<NT>::MAX; ++i)
             if (i < m) {
@@ -402,12 +417,16 @@ template <typename T>
 __device__ __forceinline__ T wilkinson_fast1(T h0, T h1, T b)
 {
     const T b2 = b * b;
-    T d = (h0 - h1) * T(0.5);
+    const T d = (h0 - h1) * T(0.5);
     const T sb2 = (d < T(0)) ? -b2 : b2;
     const T t = fma_t(d, d, b2);
-    if (__builtin_expect(!(t > FastRange<T>::lo && t < FastRange<T>::hi), 0)) return wilkinson1<T>(h0, h1, b);
-    d = fabs_(d) + hw_sqrt(t);
-    return h1 - sb2 * hw_rcp(d);
+    const bool ok = t > FastRange<T>::lo && t < FastRange<T>::hi;
+    T sigma = h1 - sb2 * hw_rcp(fabs_(d) + hw_sqrt(t));
+    if (__builtin_expect(__any(!ok), 0)) {
+        const T s2 = wilkinson1<T>(h0, h1, b);
+        sigma = ok ? sigma : s2;
+    }
+    return sigma;
 }
 
 // One explicitly shifted QR step T <- R Q + sigma on the leading m x m block of a SYMMETRIC
