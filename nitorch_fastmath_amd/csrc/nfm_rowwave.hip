@@ -1,23 +1,30 @@
-// nfm_rowwave.hip -- orders 9..16 with ONE MATRIX PER 16 LANES (one row per lane).
+// nfm_rowwave.hip -- orders 9..16 with ONE MATRIX PER 16 / R LANES (R = 1, 2 or 4 rows per lane).
 //
 // A 16x16 float64 matrix is 512 dwords: the whole register file of a lane.  The lane-per-matrix
-// kernels of nfm_large.hip therefore spill at float64 orders 14..16 (0.4-1.5 TB/s) and run at one
-// wave per SIMD long before that.  Here a matrix is spread over the 16 lanes of a DPP row: lane r
-// holds row r (N values = 2N dwords), a wavefront works on 4 matrices, a 256-lane workgroup on 16.
+// kernels of nfm_large.hip therefore spilled at float64 orders 13..16 (0.4-1.5 TB/s) and run at
+// one wave per SIMD long before that.  Here a matrix is spread over the 16 / R lanes of a DPP row:
+// a lane holds R rows (row ids lane + t * 16 / R), a wavefront works on 4 R matrices, a workgroup
+// of 256 / R lanes on 16.
 //
-//   * pivot search: max over the unused rows of an integer key that orders |a_rk| = 4 DPP row
-//     rotations (row_ror 8/4/2/1) with a v_max_u32 each; the pivot lane is the lowest set bit of
-//     the group's 16 bits of a ballot;
-//   * elimination: Gauss-Jordan WITHOUT row exchanges -- the pivot row stays in its lane and is
-//     broadcast value by value with ds_bpermute (the LDS crossbar, no LDS memory), every other
-//     lane updates its row with one fma per value.  All 16 lanes work in every step, so the
-//     Gauss-Jordan form (no back substitution) is free;
-//   * inverse: the in-place Gauss-Jordan on [A | I], rows divided by their pivots at the end; lane
-//     p_k ends up with row k of A^-1 whose l-th entry belongs to column p_l (p = the pivot lane
-//     sequence), undone while writing the LDS image;
+//   * pivot search: max over the unused rows of an integer key that orders |a_rk| -- over the
+//     lane's own rows first, then over the lanes of the matrix by DPP (row_ror / quad_perm /
+//     row_half_mirror) with a v_max_u32 each; the pivot lane is the lowest set bit of the
+//     matrix's bits of a ballot;
+//   * elimination: Gauss-Jordan WITHOUT row exchanges -- the pivot row stays where it is and
+//     reaches the other lanes value by value, by ds_bpermute (the LDS crossbar, no LDS memory) or
+//     through a per-matrix LDS slot (template LB); every row is updated with one fma per value
+//     (the pivot row's own multiplier is 0).  All lanes work in every step, so the Gauss-Jordan
+//     form (no back substitution) is free.  One broadcast serves the R rows of every lane: time is
+//     proportional to the broadcasts per matrix, which is why R = 2 / 4 beat R = 1 until
+//     registers bite (profiles/r02/rowwave_table.md, rowwave_counters.md);
+//   * inverse: the in-place Gauss-Jordan on [A | I], rows divided by their pivots at the end; the
+//     lane that pivoted at step k ends up with row k of A^-1 whose l-th entry belongs to the
+//     column = row id of the pivot of step l, undone while writing the LDS image;
+//   * determinant: product of the pivots, sign from the Lehmer code of the pivot sequence;
 //   * HBM traffic: the tile's records are contiguous, so they are streamed with 16-byte accesses
-//     through an LDS image (rows padded to an odd number of 16-byte slots: conflict-free
-//     ds_read_b128 / ds_write_b128 by 16 lanes holding 16 rows), exactly the algorithmic bytes.
+//     through an LDS image (rows padded to an odd number of 16-byte slots), exactly the
+//     algorithmic bytes; a base that is only element-aligned takes element accesses.
+//   The form (R, LB) of every (dtype, order, op) is rowwave_choice (nfm_rowwave.hpp).
 //
 // 1 / pivot is v_rcp + Newton steps (2 for float64, 1 for float32: <= 1.5 ulp) instead of the
 // IEEE division sequence; pivots are the same as the CPU restatement's (partial pivoting, first
@@ -34,8 +41,7 @@
 namespace nfm {
 namespace roww {
 
-constexpr int G = 16;    // lanes per matrix = one DPP row
-constexpr int MPB = 16;  // matrices per 256-lane workgroup
+constexpr int MPB = 16; // matrices per workgroup
 
 enum { RW_SOLVE_SYM = 0, RW_INV_SYM, RW_INVDIAG_SYM, RW_DET_SYM, RW_INV_GEN, RW_DET_GEN };
 
