@@ -64,7 +64,11 @@ def parse(argv=None):
                    help='also time the OPTIONAL epilogue: all-gather of the per-rank outputs over xGMI (reported '
                         'separately as gather_ms; never part of value)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                   help='gloo = CPU launcher self-test, only with --workload null')
+                   help='gloo = CPU launcher self-test (--workload null), or a rehearsal with --share-gpu')
+    p.add_argument('--share-gpu', action='store_true',
+                   help='REHEARSAL of the N > 1 path on a one-GPU box: every rank runs the real workload on cuda:0 '
+                        '(needs --backend gloo: RCCL refuses two ranks on one device).  The line says so '
+                        '(config.rehearsal) and is not a scaling measurement.')
     return p.parse_args(argv)
 
 
@@ -428,7 +432,7 @@ def stored_traffic(workload, units, layout):
     return rec.get('hbm_bytes_per_launch'), f'profiles/traffic_{workload}.json (stored rocprofv3 --pmc pass, not this run)'
 
 
-def census(world, device, dist):
+def census(world, device, dist, comm_device=None):
     """every rank contributes one count and its device identity: proves N ranks on N distinct GPUs"""
     import torch
     if device.type == 'cuda':
@@ -441,7 +445,7 @@ def census(world, device, dist):
         ident = {'rank': int(os.environ.get('RANK', '0')), 'index': None, 'name': 'cpu', 'uuid': '', 'pci': ''}
     if world == 1:
         return 1, [ident]
-    ones = torch.ones(1, dtype=torch.int64, device=device)
+    ones = torch.ones(1, dtype=torch.int64, device=comm_device if comm_device is not None else device)
     dist.all_reduce(ones)
     idents = [None] * world
     dist.all_gather_object(idents, ident)
@@ -459,21 +463,23 @@ def run_rank(a):
               f'{a.gpus} GPUs (launch with --nproc-per-node {a.gpus}, or unset WORLD_SIZE and let bench.py '
               f'start the ranks)', file=sys.stderr)
         return 2
-    on_gpu = a.backend == 'nccl'
-    if not on_gpu and a.workload != 'null':
-        print('bench.py: --backend gloo only runs the launcher self-test (--workload null); '
-              'the product has no CPU path', file=sys.stderr)
+    if a.share_gpu and a.backend != 'gloo':
+        print('bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)', file=sys.stderr)
         return 2
+    on_gpu = a.backend == 'nccl' or a.share_gpu
+    if not on_gpu and a.workload != 'null':
+        print('bench.py: --backend gloo only runs the launcher self-test (--workload null) or a --share-gpu '
+              'rehearsal; the product has no CPU path', file=sys.stderr)
+        return 2
+    from nitorch_fastmath_amd.shard import max_over_ranks
     if on_gpu:
-        from nitorch_fastmath_amd.shard import max_over_ranks
-        device = torch.device('cuda', local_rank if world > 1 else 0)
+        device = torch.device('cuda', 0 if (a.share_gpu or world == 1) else local_rank)
         torch.cuda.set_device(device)
     else:
-        from nitorch_fastmath_amd.shard import max_over_ranks
         device = torch.device('cpu')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if on_gpu:
+        if a.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -519,11 +525,11 @@ def run_rank(a):
     marks.append(event())
     barrier()
     wall = time.perf_counter() - t0
-    wall = max_over_ranks(wall, device=device)
+    wall = max_over_ranks(wall, device=device if a.backend == 'nccl' else None)
     per_step = sorted(elapsed_ms(marks[i], marks[i + 1]) for i in range(a.steps))
     kern_ms = elapsed_ms(marks[0], marks[-1]) / a.steps      # average launch duration on the stream
     median_ms, min_ms = per_step[len(per_step) // 2], per_step[0]
-    ranks_seen, devices = census(world, device, dist)
+    ranks_seen, devices = census(world, device, dist, None if a.backend == 'nccl' else torch.device('cpu'))
     gather_ms = None
     if a.gather and w.output is not None and world > 1:
         from nitorch_fastmath_amd.shard import gather_outputs
@@ -531,7 +537,7 @@ def run_rank(a):
         tg = time.perf_counter()
         full = gather_outputs(w.output.contiguous(), world * w.output.shape[0])
         barrier()
-        gather_ms = max_over_ranks(time.perf_counter() - tg, device=device) * 1e3
+        gather_ms = max_over_ranks(time.perf_counter() - tg, device=device if a.backend == 'nccl' else None) * 1e3
         del full
 
     if rank != 0:
@@ -551,7 +557,10 @@ def run_rank(a):
                    else ('external (WORLD_SIZE in env)' if world > 1 else 'single process')},
         'ranks_seen': ranks_seen, 'distinct_devices': distinct, 'devices': devices,
     }
-    if ranks_seen != world or (on_gpu and distinct != world):
+    if a.share_gpu:
+        line['config']['rehearsal'] = (f'{world} ranks share cuda:0 over gloo: exercises the N > 1 code path on a one-GPU '
+                                       'box; NOT a scaling measurement')
+    if ranks_seen != world or (on_gpu and not a.share_gpu and distinct != world):
         print(f'bench.py: census mismatch: {ranks_seen} ranks on {distinct} distinct devices for world {world}',
               file=sys.stderr)
         rc = 3

@@ -41,3 +41,17 @@ def test_other_workloads_run(dev):
     for w, n in (('sym_solve6', '1e6'), ('batchinv8', '2e5'), ('nansum', '4e7'), ('sym_invert3', '1e5')):
         d = run_bench('--workload', w, '--steps', '2', '--warmup', '1', '--n', n, '--no-cpu')
         assert d['value'] > 0 and 'cpu_baseline' not in d and d['roofline']['achieved'] > 0
+
+
+def test_multi_rank_rehearsal_on_one_gpu(dev):
+    """the N > 1 path end to end with the real workload: `--gpus 3` self-launches three ranks that
+    share cuda:0 over gloo (RCCL refuses two ranks on one device, so this is a rehearsal of the code
+    path -- device selection, barrier, max-over-ranks wall time, census, whole-job value -- not a
+    scaling measurement; the line says so)"""
+    d = run_bench('--gpus', '3', '--steps', '5', '--warmup', '2', '--n', '4e6', '--backend', 'gloo', '--share-gpu',
+                  '--settle-ms', '20')
+    assert d['n_gpus'] == 3 and d['ranks_seen'] == 3 and d['config']['parallelism'] == 'batch-shard x3'
+    assert 'rehearsal' in d['config'] and d['config']['launcher'].startswith('bench.py')
+    assert sorted(x['rank'] for x in d['devices']) == [0, 1, 2] and d['distinct_devices'] == 1
+    assert abs(d['value'] - 3 * 4e6 * 5 / (d['ms_per_step'] * 5e-3)) / d['value'] < 1e-6
+    assert 'cpu_baseline' not in d and 'parity' not in d and d['roofline']['achieved'] > 0
