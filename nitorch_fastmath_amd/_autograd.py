@@ -14,7 +14,7 @@ import ctypes
 import torch
 from torch.autograd.function import once_differentiable
 from . import _lib
-from ._dispatch import Batch, dtype_code, expand_batch, stream_ptr, broadcast_shapes
+from ._dispatch import on_device, Batch, dtype_code, expand_batch, stream_ptr, broadcast_shapes
 
 
 def needs_grad(*tensors):
@@ -36,7 +36,7 @@ def sym_outer2(x, y, neg=False):
     out = torch.empty(tuple(batch) + (M * (M + 1) // 2,), dtype=dtype, device=dev)
     b = Batch(batch, [expand_batch(batch, x, 1), expand_batch(batch, y, 1), out], [1, 1, 1])
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_outer2(dtype_code(dtype), M, int(neg), b.n_outer, b.n_inner,
                                              ctypes.byref(o[0]), ctypes.byref(o[1]), ctypes.byref(o[2]),
                                              stream_ptr(dev)))

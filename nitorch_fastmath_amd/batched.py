@@ -12,7 +12,7 @@ __all__ = ['batchmatvec', 'batchdet', 'batchinv']
 import ctypes
 import torch
 from . import _lib
-from ._dispatch import (Batch, broadcast_shapes, common_dtype, dtype_code, expand_batch, no_grad_required,
+from ._dispatch import (same_dtype, on_device, Batch, broadcast_shapes, common_dtype, dtype_code, expand_batch, no_grad_required,
                         require_gpu, stream_ptr)
 
 
@@ -22,7 +22,7 @@ def _prep(*tensors):
     no_grad_required(*tensors)
     dtype = common_dtype(None, *tensors)
     dtype_code(dtype)
-    return dev, dtype, [t.to(dtype) for t in tensors]
+    return dev, dtype, same_dtype(tensors, dtype)
 
 
 def _like_or_contiguous(like, shape, dtype, dev):
@@ -53,7 +53,7 @@ def batchdet(a):
     out = torch.empty(batch, dtype=dtype, device=dev)
     b = Batch(batch, [a, out], [2, 0], pack=n > 8)
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_batch_det(dtype_code(dtype), n, b.n_outer, b.n_inner,
                                             ctypes.byref(o[0]), ctypes.byref(o[1]), stream_ptr(dev)))
     b.finish()
@@ -83,7 +83,7 @@ def batchinv(a, perturb=False):
     b = Batch(batch, [a, out], [2, 2], pack=n > 8)
     o = b.operands
     flags = _lib.FLAG_TS_PERTURB if perturb else 0
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_batch_inv(dtype_code(dtype), n, flags, b.n_outer, b.n_inner,
                                             ctypes.byref(o[0]), ctypes.byref(o[1]), stream_ptr(dev)))
     b.finish()
@@ -106,7 +106,7 @@ def batchmatvec(mat, vec):
     out = _like_or_contiguous(vec if m == n else None, tuple(batch) + (m,), dtype, dev)
     b = Batch(batch, [expand_batch(batch, mat, 2), expand_batch(batch, vec, 1), out], [2, 1, 1])
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_batch_matvec(dtype_code(dtype), m, n, b.n_outer, b.n_inner,
                                                ctypes.byref(o[0]), ctypes.byref(o[1]),
                                                ctypes.byref(o[2]), stream_ptr(dev)))

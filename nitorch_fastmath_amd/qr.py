@@ -37,7 +37,7 @@ __all__ = [
 import ctypes
 import torch
 from . import _lib
-from ._dispatch import Batch, dtype_code, expand_batch, no_grad_required, require_gpu, stream_ptr, broadcast_shapes
+from ._dispatch import same_dtype, on_device, Batch, dtype_code, expand_batch, no_grad_required, require_gpu, stream_ptr, broadcast_shapes
 from .utils import ensure_list
 
 # default arithmetic of the QR sweeps of eig_sym: 'fast' or 'reference' (module docstring)
@@ -54,7 +54,7 @@ def _prep(*tensors):
     if dtype.is_complex:
         raise TypeError('nitorch_fastmath_amd.qr supports real float32/float64 matrices only')
     dtype_code(dtype)
-    return dev, dtype, [t.to(dtype) for t in tensors]
+    return dev, dtype, same_dtype(tensors, dtype)
 
 
 def _check_finite(check, *tensors):
@@ -84,7 +84,7 @@ def _run(fn, args_before, batch, inputs, ncomp, dtype, dev, out):
     """Collapse the batch of `inputs`, call `fn(*args_before, n_outer, n_inner, *operands, out_ptr, stream)`."""
     b = Batch(batch, list(inputs) + [_dummy(batch, dtype, dev)], list(ncomp) + [0])
     ops = [ctypes.byref(o) if o is not None else None for o in b.operands[:-1]]
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(fn(*args_before, b.n_outer, b.n_inner, *ops, out.data_ptr(), stream_ptr(dev)))
 
 
@@ -161,12 +161,12 @@ def rq_hessenberg(h, u=None, inplace=False, check_finite=True):
     L = _lib.lib()
     if u is None:
         b = Batch(batch, [expand_batch(batch, h, 2), _dummy(batch, dtype, dev)], [2, 0])
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _lib.check(L.nfm_qr_rq_hessenberg(dtype_code(dtype), n, 0, b.n_outer, b.n_inner,
                                               ctypes.byref(b.operands[0]), None, out.data_ptr(), stream_ptr(dev)))
         return out.unflatten(-1, (n, n))
     b = Batch(batch, [expand_batch(batch, h, 2), expand_batch(batch, u, 2), _dummy(batch, dtype, dev)], [2, 2, 0])
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(L.nfm_qr_rq_hessenberg(dtype_code(dtype), n, 0, b.n_outer, b.n_inner,
                                           ctypes.byref(b.operands[0]), ctypes.byref(b.operands[1]),
                                           out.data_ptr(), stream_ptr(dev)))
@@ -269,7 +269,7 @@ def householder_apply(a, u, k=None, side='both', inverse=False, inplace=False, c
     for uk in us:
         m = uk.shape[-1]
         b = Batch(batch, [expand_batch(batch, uk, 1), out], [1, 2])
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _lib.check(L.nfm_qr_householder_apply(dtype_code(dtype), n, m, _lib.SIDE[side.lower()], b.n_outer, b.n_inner,
                                                   ctypes.byref(b.operands[1]), ctypes.byref(b.operands[0]),
                                                   stream_ptr(dev)))
@@ -307,7 +307,7 @@ def givens_apply(a, c, s, i=0, j=None, side='both', inplace=False, check_finite=
     batch = vshape[:-1]
     out = expand_batch(batch, a, 2).clone(memory_format=torch.contiguous_format)
     b = Batch(batch, [c.expand(vshape), s.expand(vshape), out], [1, 1, 2])
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_qr_givens_apply(dtype_code(dtype), n, _lib.SIDE[side.lower()], int(i), int(j),
                                                   b.n_outer, b.n_inner, ctypes.byref(b.operands[2]),
                                                   ctypes.byref(b.operands[0]), ctypes.byref(b.operands[1]),

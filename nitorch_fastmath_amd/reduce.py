@@ -27,7 +27,7 @@ __all__ = [
 import builtins
 import torch
 from . import _lib
-from ._dispatch import dtype_code, no_grad_required, require_gpu, stream_ptr
+from ._dispatch import on_device, dtype_code, no_grad_required, require_gpu, stream_ptr
 from .utils import ensure_list, ind2sub
 
 
@@ -175,7 +175,7 @@ def _reduce(op, input, dim, keepdim, out_dtype, want_idx=False):
         x = input if input.is_contiguous() else input.contiguous()
         out = torch.empty([], dtype=out_dtype, device=dev)
         ws, wsn = _workspace(dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _lib.check(L.nfm_reduce_all(code, op, ocode, x.numel(), x.data_ptr(), ws.data_ptr(), wsn,
                                         out.data_ptr(), stream_ptr(dev)))
         if keepdim:
@@ -189,7 +189,7 @@ def _reduce(op, input, dim, keepdim, out_dtype, want_idx=False):
     if red == 0 and op in (_lib.RED_NANMAX, _lib.RED_NANMIN, _lib.RED_MAX, _lib.RED_MIN):
         raise IndexError('cannot take the max/min over an empty dimension')
     ws, wsn = _workspace(dev, L.nfm_reduce_dim_workspace_bytes(code, op, outer, red, inner, int(want_idx)))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(L.nfm_reduce_dim(code, op, ocode, outer, red, inner, x.data_ptr(),
                                     ws.data_ptr() if ws is not None else None, wsn, out.data_ptr(),
                                     idx.data_ptr() if idx is not None else None, stream_ptr(dev)))
@@ -318,7 +318,7 @@ def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_
     for lo in range(0, rows, builtins.max(step, 1)):
         hi = builtins.min(rows, lo + step)
         ws, wsn = _workspace(dev, L.nfm_reduce_median_workspace_bytes(hi - lo, red))
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _lib.check(L.nfm_reduce_median(code, int(bool(omitnan)), hi - lo, red, x[lo:hi].data_ptr(),
                                            ws.data_ptr() if ws is not None else None, wsn, val[lo:hi].data_ptr(),
                                            idx[lo:hi].data_ptr() if idx is not None else None, stream_ptr(dev)))
@@ -363,7 +363,7 @@ def _moments(input, dim, keepdim):
     subshape = [shape[d] for d in kept]
     out = torch.zeros(subshape + [4], dtype=torch.float64, device=dev)
     ws, wsn = _workspace(dev, L.nfm_reduce_moments_workspace_bytes(code, outer, red, inner))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(L.nfm_reduce_moments(code, outer, red, inner, x.data_ptr(),
                                         ws.data_ptr() if ws is not None else None, wsn,
                                         out.data_ptr(), stream_ptr(dev)))
@@ -434,7 +434,7 @@ def _stat(kind, input, dim, keepdim, omitnan, unbiased, out_dtype):
         out.fill_(float('nan'))
     stat = kind | (_STAT_OMITNAN if omitnan else 0) | (_STAT_UNBIASED if unbiased else 0)
     ws, wsn = _workspace(dev, L.nfm_reduce_moments_workspace_bytes(code, outer, red, inner))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(L.nfm_reduce_stat(code, stat, ocode, outer, red, inner, x.data_ptr(),
                                      ws.data_ptr() if ws is not None else None, wsn,
                                      out.data_ptr(), stream_ptr(dev)))

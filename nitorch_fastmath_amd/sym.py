@@ -29,7 +29,7 @@ import ctypes
 from math import sqrt
 import torch
 from . import _lib
-from ._dispatch import (Batch, broadcast_shapes, common_dtype, dtype_code, expand_batch, no_grad_required,
+from ._dispatch import (same_dtype, on_device, Batch, broadcast_shapes, common_dtype, dtype_code, expand_batch, no_grad_required,
                         require_gpu, stream_ptr)
 
 
@@ -65,7 +65,7 @@ def _prep(dtype, *tensors):
     no_grad_required(*tensors)
     dtype = common_dtype(dtype, *tensors)
     dtype_code(dtype)
-    return dev, dtype, [None if t is None else t.to(dtype) for t in tensors]
+    return dev, dtype, same_dtype(tensors, dtype)
 
 
 def _alloc_out(out, shape, dtype, device, like=None):
@@ -78,14 +78,6 @@ def _alloc_out(out, shape, dtype, device, like=None):
             cand = torch.empty_like(like, dtype=dtype)      # preserve_format keeps dense strides
             if cand.stride() == like.stride():
                 return cand, None
-        # a contiguous operand that starts inside a 16-byte vector (rows i0.. of a larger tensor)
-        # hands its phase on, so that peeling a few records aligns inputs AND output together
-        if (like is not None and tuple(like.shape) == tuple(shape) and like.is_contiguous()
-                and like.dtype == dtype and like.data_ptr() % 16 != 0 and like.numel() > 0):
-            es = like.element_size()
-            off = (like.data_ptr() % 16) // es
-            n = like.numel()
-            return torch.empty(n + 16 // es, dtype=dtype, device=device)[off:off + n].view(shape), None
         return torch.empty(shape, dtype=dtype, device=device), None
     if tuple(out.shape) != tuple(shape):
         raise ValueError(f'out has shape {tuple(out.shape)}, expected {tuple(shape)}')
@@ -124,7 +116,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
     b = Batch(batch, ops, ncs, pack=N > 8 and kind == _lib.MAT_SYM)
     o = b.operands
     o_inp = ctypes.byref(o[2]) if inp is not None else None
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_matvec(
             dtype_code(dtype), N, kind, mode, b.n_outer, b.n_inner, ctypes.byref(o[0]),
             ctypes.byref(o[1]), o_inp, ctypes.byref(o[-1]), stream_ptr(dev)))
@@ -234,7 +226,7 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
             raise ValueError('eps is empty')
         e = (e + [e[-1]] * N)[:N]
         eps_p = (ctypes.c_double * _lib.MAX_DIM)(*(e + [0.0] * (_lib.MAX_DIM - N)))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_solve(
             dtype_code(dtype), N, kind, b.n_outer, b.n_inner, ctypes.byref(o[0]), ctypes.byref(o[1]),
             ctypes.byref(o[2]), eps_p, stream_ptr(dev)))
@@ -274,7 +266,7 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
     out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=mat if M <= 8 else None)
     b = Batch(batch, [mat, out], [1, 1], pack=M > 8 and not diag)
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_invert(
             dtype_code(dtype), M, int(bool(diag)), b.n_outer, b.n_inner, ctypes.byref(o[0]),
             ctypes.byref(o[1]), stream_ptr(dev)))
@@ -307,7 +299,7 @@ def sym_det(mat, dtype=None, out=None):
     out, _ = _alloc_out(out, tuple(batch), dtype, dev)
     b = Batch(batch, [mat, out], [1, 0], pack=M > 8)
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_det(
             dtype_code(dtype), M, b.n_outer, b.n_inner, ctypes.byref(o[0]), ctypes.byref(o[1]),
             stream_ptr(dev)))
@@ -335,7 +327,7 @@ def sym_to_full(mat, dtype=None, out=None):
     out, _ = _alloc_out(out, tuple(batch) + (M, M), dtype, dev)
     b = Batch(batch, [mat, out], [1, 2])
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_to_full(
             dtype_code(dtype), M, b.n_outer, b.n_inner, ctypes.byref(o[0]), ctypes.byref(o[1]),
             stream_ptr(dev)))
@@ -363,7 +355,7 @@ def sym_outer(x, dtype=None, out=None):
     out, _ = _alloc_out(out, tuple(batch) + (M * (M + 1) // 2,), dtype, dev)
     b = Batch(batch, [x, out], [1, 1])
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_outer(
             dtype_code(dtype), M, b.n_outer, b.n_inner, ctypes.byref(o[0]), ctypes.byref(o[1]),
             stream_ptr(dev)))
@@ -396,7 +388,7 @@ def sym_matmul(j, h, dtype=None, out=None):
     out, _ = _alloc_out(out, tuple(batch) + (d * (d + 1) // 2,), dtype, dev)
     b = Batch(batch, [expand_batch(batch, j, 2), expand_batch(batch, h, 1), out], [2, 1, 1])
     o = b.operands
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_matmul(
             dtype_code(dtype), k, d, hk, b.n_outer, b.n_inner, ctypes.byref(o[0]), ctypes.byref(o[1]),
             ctypes.byref(o[2]), stream_ptr(dev)))
@@ -440,7 +432,7 @@ def sym_matmul_solve(j, h, g, eps=None, dtype=None, out=None):
             raise ValueError('eps is empty')
         e = (e + [e[-1]] * d)[:d]
         eps_p = (ctypes.c_double * _lib.MAX_DIM)(*(e + [0.0] * (_lib.MAX_DIM - d)))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_matmul_solve(
             dtype_code(dtype), k, d, hk, b.n_outer, b.n_inner, ctypes.byref(o[0]), ctypes.byref(o[1]),
             ctypes.byref(o[2]), ctypes.byref(o[3]), eps_p, stream_ptr(dev)))

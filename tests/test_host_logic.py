@@ -82,9 +82,8 @@ def test_output_allocation_policy_needs_no_gpu_to_decide():
     out, _ = _alloc_out(None, (1000, 4), torch.float32, cpu, like=torch.zeros(1000, 4))
     assert out.is_contiguous()
     sl = torch.zeros(1001, 6)[1:]                        # rows 1.. : starts 24 B into an aligned buffer
-    assert sl.data_ptr() % 16 == 8
     out, _ = _alloc_out(None, (1000, 6), torch.float32, cpu, like=sl)
-    assert out.is_contiguous() and out.data_ptr() % 16 == sl.data_ptr() % 16     # same phase
+    assert out.is_contiguous()        # no phase games any more: wide global accesses take any element offset
     with pytest.raises(ValueError):
         _alloc_out(torch.zeros(3, 4), (1000, 4), torch.float32, cpu)
 
@@ -105,3 +104,24 @@ def test_utils_only_holds_hot_path_helpers():
     lst = [1]
     assert U.ensure_list(lst, 3) is not None and lst == [1, 1, 1]      # lists are padded in place, like upstream
 
+
+
+def test_batch_fast_path_equals_the_general_collapse():
+    """contiguous full-shape operands skip the stride collapse (launch-bound small batches): the
+    operand descriptors must be the ones the general path computes"""
+    from nitorch_fastmath_amd._dispatch import Batch
+    from nitorch_fastmath_amd import _dispatch as D
+
+    def fields(b):
+        return [(o.stride_outer, o.stride_inner, o.stride_row, o.stride_col) for o in b.operands], b.n_outer, b.n_inner
+    for batch, comps, ncomp in (((7, 5), [(6,), (3,), ()], [1, 1, 0]), ((11,), [(4, 4), (4,)], [2, 1]),
+                                ((1,), [(10,), (4,)], [1, 1]), ((2, 1, 3), [(8, 8), (8, 8)], [2, 2])):
+        ts = [torch.zeros(tuple(batch) + c) for c in comps]
+        fast = fields(Batch(batch, ts, ncomp))
+        saved = torch.Tensor.is_contiguous
+        try:                                       # force the general path on the same tensors
+            torch.Tensor.is_contiguous = lambda self, *a, **k: False
+            slow = fields(Batch(batch, ts, ncomp))
+        finally:
+            torch.Tensor.is_contiguous = saved
+        assert fast == slow, (batch, fast, slow)
