@@ -223,5 +223,8 @@ class Batch:
 
 def expand_batch(batch_shape, t, ncomp):
     """Expand `t` (batch dims + ncomp component dims) to the broadcast batch shape (a view)."""
-    comp = tuple(t.shape[t.dim() - ncomp:]) if ncomp else ()
+    nb = t.dim() - ncomp
+    if t.shape[:nb] == tuple(batch_shape):       # nothing to broadcast: the common case, and `expand` is 1.5 us
+        return t
+    comp = tuple(t.shape[nb:]) if ncomp else ()
     return t.expand(tuple(batch_shape) + comp)
