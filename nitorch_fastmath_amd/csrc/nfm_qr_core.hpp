@@ -113,12 +113,13 @@ template <typename T>
 __device__ __forceinline__ void givens_fast1(T x, T y, T &c, T &s)
 {
     const T r2 = fma_t(x, x, y * y);
-    const bool ok = r2 > FastRange<T>::lo && r2 < FastRange<T>::hi;
+    // lanes that need the IEEE form: squared norm outside the safe range, or an axis-aligned pair
+    // (x y == 0) -- that one is an exact rotation in the reference (x / |x| = +-1) and must stay
+    // exact, so that diagonal / already deflated input comes back bit for bit
+    const bool ok = r2 > FastRange<T>::lo && r2 < FastRange<T>::hi && x * y != T(0);
     const T inv = rsq_nr(r2);
-    // an axis-aligned pair is an exact rotation in the reference (x / |x| = +-1): keep it exact, so
-    // that diagonal / already deflated input comes back bit for bit
-    c = (y == T(0)) ? copysign_t(T(1), x) : x * inv;
-    s = (x == T(0)) ? -copysign_t(T(1), y) : -(y * inv);
+    c = x * inv;
+    s = -(y * inv);
     if (__builtin_expect(__any(!ok), 0)) {
         T c2, s2;
         givens1<T>(x, y, c2, s2);
