@@ -101,8 +101,13 @@ template <typename T>
 __device__ __forceinline__ T pivot_recip(T pv)
 {
     const T a = fabs_(pv);
-    if (__builtin_expect(!(a > T(1e-30) && a < T(1e30)), 0)) return T(1) / pv;
-    return recip(pv);
+    const bool ok = a > T(1e-30) && a < T(1e30);
+    T r = recip(pv);
+    if (__builtin_expect(__any(!ok), 0)) { // a uniform vote: no exec-mask juggling on the common path
+        const T e = T(1) / pv;
+        r = ok ? r : e;
+    }
+    return r;
 }
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
