@@ -12,7 +12,8 @@
 //   * records of exactly 4/8/16 bytes need no transpose (one packed access per lane);
 //   * component-major ("SoA", channel-first) operands stream each component's run with
 //     16-byte loads into an LDS image [component][TILE] (SoaIO);
-//   * anything else (broadcast operands, irregular strides) is read/written element by
+//   * records contiguous inside at any batch stride (strided, padded, broadcast): 16-byte accesses
+//     per lane (MODE_PACKED); anything else is read/written element by
 //     element by each lane (rec_direct_load/store in nfm_record_kernel.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -432,6 +433,37 @@ inline bool soa_ok(const nfm_operand *op, int C, int rows, size_t elem)
     if (op->ptr == nullptr || C < 2) return false;
     if (reinterpret_cast<uintptr_t>(op->ptr) % elem != 0) return false;
     return op->stride_inner == 1;
+}
+
+// Is the record contiguous inside (whatever the batch strides, 0 included)?  Then a lane moves it
+// with whole 16-byte accesses (MODE_PACKED).  Records of fewer than two elements gain nothing.
+inline bool packed_ok(const nfm_operand *op, int C, int rows, int cols, size_t elem)
+{
+    if (op->ptr == nullptr || C < 2) return false;
+    if (reinterpret_cast<uintptr_t>(op->ptr) % elem != 0) return false;
+    if (rows > 1) return op->stride_row == cols && op->stride_col == 1;
+    return op->stride_col == 1;
+}
+
+// the covering span of a step-2 record is live in registers all at once: up to 72 of them
+__host__ __device__ constexpr bool packed2_fits(int C, size_t elem) { return C > 1 && (2 * C - 1) * elem <= 288; }
+
+// elements of the record two apart (and rows of a matrix record 2 * cols apart): the covering span
+// of 2C - 1 elements is fetched packed (inputs only: the gaps are not ours to write)
+inline bool packed2_ok(const nfm_operand *op, int C, int rows, int cols, size_t elem)
+{
+    if (op->ptr == nullptr || C < 2) return false;
+    if (reinterpret_cast<uintptr_t>(op->ptr) % elem != 0) return false;
+    if (rows > 1) return op->stride_row == 2 * cols && op->stride_col == 2;
+    return op->stride_col == 2;
+}
+
+// a full matrix stored transposed (column-major inside the record)
+inline bool packedt_ok(const nfm_operand *op, int rows, int cols, size_t elem)
+{
+    if (op->ptr == nullptr || rows < 2 || cols < 2) return false;
+    if (reinterpret_cast<uintptr_t>(op->ptr) % elem != 0) return false;
+    return op->stride_row == 1 && op->stride_col == rows;
 }
 
 inline Opnd make_opnd(const nfm_operand *op, int tiled)

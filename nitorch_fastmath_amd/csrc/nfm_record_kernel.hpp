@@ -2,7 +2,7 @@
 //
 //   rec_kernel<T, Op, KIND>: up to three input records (A, B, C) and one output record
 //   per batch element; Op::apply() is the in-register arithmetic.  Each operand
-//   independently takes one of four movement modes (LDS-transposed AoS tile, packed
+//   independently takes one of five movement modes (LDS-transposed AoS tile, packed
 //   per-lane access, LDS component-major tile, strided per-lane access); the choice is a
 //   wave-uniform kernel argument (or a compile-time constant in the FAST kernel), so
 //   there is no divergence.
@@ -33,7 +33,15 @@ struct Rec {
 using NoRec = Rec<0, 0>;
 
 // how an operand is moved (wave-uniform kernel argument Opnd::tiled)
-enum { MODE_STRIDED = 0, MODE_TILED = 1, MODE_VEC = 2, MODE_SOA = 3 };
+// MODE_PACKED: records that are contiguous INSIDE but sit at any batch stride (every k-th record
+// of a field, rows of a cropped field, a padded record, a broadcast operand): the lane fetches
+// its record with ceil(C / 4) element-aligned 16-byte accesses instead of C scalar ones.
+// MODE_PACKED2: the same for INPUT records whose elements are two apart (the real parts of a complex
+// field, one of two interleaved fields): the lane fetches the covering span and keeps every other
+// element.  MODE_PACKEDT: full matrices stored transposed (a.mT): packed accesses, the transpose is a
+// renaming of registers.
+enum { MODE_STRIDED = 0, MODE_TILED = 1, MODE_VEC = 2, MODE_SOA = 3, MODE_PACKED = 4, MODE_PACKED2 = 5,
+       MODE_PACKEDT = 6 };
 
 template <typename T, class R, int TILE>
 struct RecIO {
@@ -131,22 +139,119 @@ struct RecLayout {
     static constexpr int gtotal = gO + O::lds_any;
 };
 
-template <typename T, class R>
-__device__ __forceinline__ void rec_direct_load(const Opnd &op, int64_t o, int64_t i, bool valid, T (&r)[R::Cs])
+// One record of C back-to-back elements at p, moved with the widest element-aligned accesses:
+// whole 16-byte vectors, then an 8-byte pair (float), then a single element.  Plain (cached)
+// accesses on purpose: when the batch stride leaves gaps between records, the 2-3 accesses of a
+// lane -- and the neighbouring lanes' -- land in the same 128-byte lines one after the other.
+template <typename T, int C>
+__device__ __forceinline__ void packed_load(const T *p, T (&r)[C])
 {
-    const T *p = reinterpret_cast<const T *>(op.ptr) + o * op.so + i * op.si;
+    using VG = typename VecOf<T>::gtype;
+    constexpr int kVec = VecOf<T>::N;
 #pragma unroll
-    for (int a = 0; a < R::R; ++a)
+    for (int s = 0; s < C / kVec; ++s) {
+        const VG v = *reinterpret_cast<const VG *>(p + s * kVec);
 #pragma unroll
-        for (int b = 0; b < R::Cc; ++b) r[a * R::Cc + b] = valid ? p[a * op.sr + b * op.sc] : T(1);
+        for (int k = 0; k < kVec; ++k) r[s * kVec + k] = v[k];
+    }
+    constexpr int done = (C / kVec) * kVec;
+    if constexpr (sizeof(T) == 4 && C - done >= 2) {
+        using P2 = typename PackOf<T, 2>::type;
+        const P2 v = *reinterpret_cast<const P2 *>(p + done);
+        r[done] = v[0];
+        r[done + 1] = v[1];
+        if constexpr (C - done == 3) r[done + 2] = p[done + 2];
+    } else if constexpr (C - done == 1) {
+        r[done] = p[done];
+    }
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void packed_store(T *p, const T (&r)[C])
+{
+    using VG = typename VecOf<T>::gtype;
+    constexpr int kVec = VecOf<T>::N;
+#pragma unroll
+    for (int s = 0; s < C / kVec; ++s) {
+        VG v;
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = r[s * kVec + k];
+        *reinterpret_cast<VG *>(p + s * kVec) = v;
+    }
+    constexpr int done = (C / kVec) * kVec;
+    if constexpr (sizeof(T) == 4 && C - done >= 2) {
+        using P2 = typename PackOf<T, 2>::type;
+        P2 v;
+        v[0] = r[done];
+        v[1] = r[done + 1];
+        *reinterpret_cast<P2 *>(p + done) = v;
+        if constexpr (C - done == 3) p[done + 2] = r[done + 2];
+    } else if constexpr (C - done == 1) {
+        p[done] = r[done];
+    }
 }
 
 template <typename T, class R>
-__device__ __forceinline__ void rec_direct_store(const Opnd &op, int64_t o, int64_t i, bool valid,
+__device__ __forceinline__ void rec_direct_load(const Opnd &op, int mode, int64_t o, int64_t i, bool valid,
+                                                T (&r)[R::Cs])
+{
+    const T *p = reinterpret_cast<const T *>(op.ptr) + o * op.so + i * op.si;
+    if (!valid) { // lanes past the end of the batch compute on ones
+#pragma unroll
+        for (int c = 0; c < R::Cs; ++c) r[c] = T(1);
+        return;
+    }
+    if (mode == MODE_PACKED) { // wave-uniform
+        packed_load<T, R::Cs>(p, r);
+        return;
+    }
+    if constexpr (packed2_fits(R::Cs, sizeof(T))) {
+        if (mode == MODE_PACKED2) { // elements two apart: fetch the covering span, keep every other one
+            T span[2 * R::Cs - 1];
+            packed_load<T, 2 * R::Cs - 1>(p, span);
+#pragma unroll
+            for (int c = 0; c < R::Cs; ++c) r[c] = span[2 * c];
+            return;
+        }
+    }
+    if constexpr (R::R > 1 && R::Cc > 1) {
+        if (mode == MODE_PACKEDT) { // stored transposed
+            T tr[R::Cs];
+            packed_load<T, R::Cs>(p, tr);
+#pragma unroll
+            for (int a = 0; a < R::R; ++a)
+#pragma unroll
+                for (int b = 0; b < R::Cc; ++b) r[a * R::Cc + b] = tr[b * R::R + a];
+            return;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < R::R; ++a)
+#pragma unroll
+        for (int b = 0; b < R::Cc; ++b) r[a * R::Cc + b] = p[a * op.sr + b * op.sc];
+}
+
+template <typename T, class R>
+__device__ __forceinline__ void rec_direct_store(const Opnd &op, int mode, int64_t o, int64_t i, bool valid,
                                                  const T (&r)[R::Cs])
 {
     T *p = reinterpret_cast<T *>(op.ptr) + o * op.so + i * op.si;
     if (valid) {
+        if (mode == MODE_PACKED) { // wave-uniform
+            packed_store<T, R::Cs>(p, r);
+            return;
+        }
+        if constexpr (R::R > 1 && R::Cc > 1) {
+            if (mode == MODE_PACKEDT) {
+                T tr[R::Cs];
+#pragma unroll
+                for (int a = 0; a < R::R; ++a)
+#pragma unroll
+                    for (int b = 0; b < R::Cc; ++b) tr[b * R::R + a] = r[a * R::Cc + b];
+                packed_store<T, R::Cs>(p, tr);
+                return;
+            }
+        }
 #pragma unroll
         for (int a = 0; a < R::R; ++a)
 #pragma unroll
@@ -167,6 +272,9 @@ struct op_streams<Op, std::void_t<decltype(Op::kStream)>> : std::bool_constant<O
 // KIND_SOA = the same for component-major (channel-first) fields: every multi-component
 // operand through the SoA image.  KIND_ANY keeps the wave-uniform run-time modes for mixed,
 // broadcast and strided operands.
+// (A fourth compile-time kind -- every operand packed per lane at run-time strides, no LDS -- was
+// built and measured in round 2: level with KIND_ANY on strided / padded records, ahead only for a
+// broadcast 6x6 matrix; not kept.  profiles/r02/layouts_packed_kernel_ab.md)
 enum { KIND_ANY = 0, KIND_AOS = 1, KIND_SOA = 2, KIND_SOAW = 3 }; // SOAW: SoA with 512-lane tiles
 
 // lanes per workgroup of a kernel variant: Op::TILE, unless the Op names another size for its
@@ -264,17 +372,17 @@ __global__ __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opn
     if constexpr (RA::used) {
         if (vA) {
             if constexpr (IA::can_vec) rec_vec_load<T, RA>(a, o, i, valid, ra);
-        } else if (!tA && !sA) rec_direct_load<T, RA>(a, o, i, valid, ra);
+        } else if (!tA && !sA) rec_direct_load<T, RA>(a, ma, o, i, valid, ra);
     }
     if constexpr (RB::used) {
         if (vB) {
             if constexpr (IB::can_vec) rec_vec_load<T, RB>(b, o, i, valid, rb);
-        } else if (!tB && !sB) rec_direct_load<T, RB>(b, o, i, valid, rb);
+        } else if (!tB && !sB) rec_direct_load<T, RB>(b, mb, o, i, valid, rb);
     }
     if constexpr (RC::used) {
         if (vC) {
             if constexpr (IC::can_vec) rec_vec_load<T, RC>(c, o, i, valid && use_c, rc);
-        } else if (!tC && !sC) rec_direct_load<T, RC>(c, o, i, valid && use_c, rc);
+        } else if (!tC && !sC) rec_direct_load<T, RC>(c, mc, o, i, valid && use_c, rc);
     }
 
     // 3. LDS transpose: park the staged vectors, one barrier, every lane picks up its records
@@ -340,7 +448,7 @@ __global__ __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opn
             return;
         }
     }
-    rec_direct_store<T, RO>(out, o, i, valid, ro);
+    rec_direct_store<T, RO>(out, mo, o, i, valid, ro);
 }
 
 // Host launcher: picks the movement mode of every operand and the kernel variant.
@@ -375,17 +483,21 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
         const bool tb = L::B::can_tile && tile_ok(pb, RB::C, RB::R, RB::Cc, n_outer, n, sizeof(T));
         const bool tc = L::C::can_tile && tile_ok(pc, RC::C, RC::R, RC::Cc, n_outer, n, sizeof(T));
         const bool to = L::O::can_tile && tile_ok(po, RO::C, RO::R, RO::Cc, n_outer, n, sizeof(T));
-        auto mode = [&](bool tiled, bool can_vec, bool can_soa, const nfm_operand *op, int C, int R, int Cc) {
+        auto mode = [&](bool tiled, bool can_vec, bool can_soa, const nfm_operand *op, int C, int R, int Cc,
+                        bool input) {
             if (tiled) return (int)MODE_TILED;
             if (can_vec && vec_ok(op, C, R, Cc, n_outer, sizeof(T))) return (int)MODE_VEC;
             if (can_soa && soa_ok(op, C, R, sizeof(T))) return (int)MODE_SOA;
+            if (packed_ok(op, C, R, Cc, sizeof(T))) return (int)MODE_PACKED;
+            if (input && packed2_fits(C, sizeof(T)) && packed2_ok(op, C, R, Cc, sizeof(T))) return (int)MODE_PACKED2;
+            if (packedt_ok(op, R, Cc, sizeof(T))) return (int)MODE_PACKEDT;
             return (int)MODE_STRIDED;
         };
         Modes m;
-        m.ma = mode(ta, L::A::can_vec, L::A::can_soa, pa, RA::C, RA::R, RA::Cc);
-        m.mb = mode(tb, L::B::can_vec, L::B::can_soa, pb, RB::C, RB::R, RB::Cc);
-        m.mc = mode(tc, L::C::can_vec, L::C::can_soa, pc, RC::C, RC::R, RC::Cc);
-        m.mo = mode(to, L::O::can_vec, L::O::can_soa, po, RO::C, RO::R, RO::Cc);
+        m.ma = mode(ta, L::A::can_vec, L::A::can_soa, pa, RA::C, RA::R, RA::Cc, true);
+        m.mb = mode(tb, L::B::can_vec, L::B::can_soa, pb, RB::C, RB::R, RB::Cc, true);
+        m.mc = mode(tc, L::C::can_vec, L::C::can_soa, pc, RC::C, RC::R, RC::Cc, true);
+        m.mo = mode(to, L::O::can_vec, L::O::can_soa, po, RO::C, RO::R, RO::Cc, false);
         m.any = ta || tb || tc || to || m.ma == MODE_SOA || m.mb == MODE_SOA || m.mc == MODE_SOA ||
                 m.mo == MODE_SOA;
         // FAST path: every used operand in its preferred mode (an absent C operand is fine)

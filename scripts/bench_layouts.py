@@ -43,6 +43,9 @@ for M in (4, 6):
     m3 = mat.view(4000, 4250, K)[:, ::2]
     v3 = vec.view(4000, 4250, M)[:, ::2]
     cases.append(('two-level batch (rows of a strided 2-D field)', m3, v3, (K + 2 * M) * 4))
+    pad = torch.zeros(n // 2, K + 2, device=dev)
+    pad[:, :K] = mat[:n // 2]
+    cases.append(('padded records: (n, K + 2)[:, :K]', pad[:, :K], vec[:n // 2], (K + 2 * M) * 4))
     mis = torch.empty(n * K + 1, device=dev)[1:].view(n, K).copy_(mat)
     cases.append(('base pointer off by 4 bytes', mis, vec, (K + 2 * M) * 4))
     cases.append(('rows 1.. of the contiguous tensors (x[1:])', mat[1:], vec[1:], (K + 2 * M) * 4))

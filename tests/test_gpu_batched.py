@@ -82,6 +82,35 @@ def test_pivoting_and_layouts(dev, oracle, n):
     assert np.array_equal(r, oracle.batch_matvec(np.broadcast_to(a[0], a.shape), v))
 
 
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6, 7, 8])
+def test_transposed_and_interleaved_records(dev, oracle, dn, n):
+    """matrices stored transposed (a.mT of a contiguous tensor: packed accesses + a renaming of
+    registers, MODE_PACKEDT) and records whose elements are two apart (the real parts of a complex
+    field: the covering span is fetched packed, MODE_PACKED2), also at a batch stride and with a tail"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(200 + n)
+    nb = 2 * 257 + 3
+    a = (rng.standard_normal((nb, n, n)) + 6 * np.eye(n)).astype(dtype)
+    v = rng.standard_normal((nb, n)).astype(dtype)
+    rinv, rdet, rmv = oracle.batch_inv(a), oracle.batch_det(a), oracle.batch_matvec(a, v)
+    at = t(a.transpose(0, 2, 1), dev).transpose(-1, -2)                 # strides (n*n, 1, n)
+    assert at.stride()[-2:] == (1, n) or n == 1
+    inv = B().batchinv(at)
+    assert relerr(inv.cpu().numpy(), rinv) <= TOL[dn]
+    assert relerr(B().batchdet(at).cpu().numpy(), rdet) <= TOL[dn]
+    assert np.array_equal(B().batchmatvec(at, t(v, dev)).cpu().numpy(), rmv)
+    assert relerr(B().batchinv(at[::2]).cpu().numpy(), rinv[::2]) <= TOL[dn]
+    z = torch.full((nb, n, n, 2), float('nan'), dtype=at.dtype, device=dev)
+    z[..., 0] = t(a, dev)
+    zv = torch.full((nb, n, 2), float('nan'), dtype=at.dtype, device=dev)
+    zv[..., 1] = t(v, dev)
+    assert relerr(B().batchinv(z[..., 0]).cpu().numpy(), rinv) <= TOL[dn]
+    assert relerr(B().batchdet(z[..., 0]).cpu().numpy(), rdet) <= TOL[dn]
+    assert np.array_equal(B().batchmatvec(z[..., 0], zv[..., 1]).cpu().numpy(), rmv)
+    assert np.array_equal(B().batchmatvec(z[::3, ..., 0], zv[::3, ..., 1]).cpu().numpy(), rmv[::3])
+
+
 @pytest.mark.parametrize('n', [2, 3, 4, 8])
 def test_matrix_first_storage_tiles(dev, oracle, n):
     """(n, n, B, S) storage viewed as (B, S, n, n): component runs -> SoA tile path; S = 340 keeps

@@ -139,6 +139,59 @@ def test_layouts(dev, oracle, dn, M):
 
 
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [2, 3, 4, 5, 6, 7])
+def test_packed_records_at_any_batch_stride(dev, oracle, dn, M):
+    """records that are contiguous inside but not back to back (every k-th record, padded records,
+    a padded output buffer) move with whole 16-byte accesses per lane (MODE_PACKED): same results,
+    and the gaps of a padded output are left alone"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    K = M * (M + 1) // 2
+    n = 3 * 257 + 5
+    mat, vec = spd_np(n, M, dtype, 90 + M)
+    ref = oracle.sym_solve(mat, vec)
+    refmv = oracle.sym_matvec(mat, vec)
+    refinv = oracle.sym_invert(mat)
+    ex = M <= 4
+    S = N().sym
+    md, vd = t(mat, dev), t(vec, dev)
+    for k in (2, 3):
+        check(S.sym_solve(md[::k], vd[::k]), ref[::k], dn, ex)
+        check(S.sym_matvec(md[::k], vd[::k].contiguous()), refmv[::k], dn, True)
+        check(S.sym_invert(md[::k]), refinv[::k], dn, ex)
+    # padded records: (n, K + 3)[:, :K] and (n, M + 1)[:, 1:] (the latter starts off a 16-byte line)
+    mp = torch.full((n, K + 3), float('nan'), dtype=md.dtype, device=dev)
+    mp[:, :K] = md
+    vp = torch.full((n, M + 1), float('nan'), dtype=md.dtype, device=dev)
+    vp[:, 1:] = vd
+    check(S.sym_solve(mp[:, :K], vp[:, 1:]), ref, dn, ex)
+    # padded output buffers: only the records are written
+    op = torch.full((n, M + 2), 7.0, dtype=md.dtype, device=dev)
+    r = S.sym_solve(md, vd, out=op[:, 1:M + 1])
+    assert r.data_ptr() == op[:, 1:M + 1].data_ptr()
+    check(op[:, 1:M + 1], ref, dn, ex)
+    assert bool((op[:, 0] == 7).all()) and bool((op[:, M + 1] == 7).all())
+    ip = torch.full((n, K + 1), 7.0, dtype=md.dtype, device=dev)
+    S.sym_invert(mp[:, :K], out=ip[:, :K])
+    check(ip[:, :K], refinv, dn, ex)
+    assert bool((ip[:, K] == 7).all())
+    # elements two apart (one of two interleaved fields): covering span fetched packed (inputs);
+    # an interleaved OUTPUT is written element by element, the other field is left alone
+    z = torch.full((n, K, 2), float('nan'), dtype=md.dtype, device=dev)
+    z[..., 1] = md
+    zv = torch.full((n, M, 2), 7.0, dtype=md.dtype, device=dev)
+    zv[..., 0] = vd
+    check(S.sym_solve(z[..., 1], zv[..., 0]), ref, dn, ex)
+    check(S.sym_solve(z[::2, :, 1], zv[::2, :, 0]), ref[::2], dn, ex)
+    S.sym_solve(z[..., 1], zv[..., 0].clone(), out=zv[..., 0])
+    check(zv[..., 0], ref, dn, ex)
+    assert bool((zv[..., 1] == 7).all())
+    # cropped 2-D field: rows of contiguous records, outer stride larger than the row
+    X, Y = 3, 257
+    m2, v2 = md[:X * Y].reshape(X, Y, K), vd[:X * Y].reshape(X, Y, M)
+    check(S.sym_solve(m2[:, 3:200], v2[:, 3:200]), ref[:X * Y].reshape(X, Y, M)[:, 3:200], dn, ex)
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
 @pytest.mark.parametrize('M', [3, 4, 6, 12])
 def test_inplace_and_eps_and_dtype(dev, oracle, dn, M):
     dtype = np.float32 if dn == 'f32' else np.float64
