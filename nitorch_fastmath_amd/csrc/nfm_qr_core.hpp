@@ -60,6 +60,12 @@ __device__ __forceinline__ bool finite_(T x)
 // 1.4e-6.  So the reference-order arithmetic stays available (FM = false: bit-identical to the
 // CPU restatement, same order, same signs) and the caller picks: `eig_sym(..., arithmetic=)`.
 // Error model and its tests: tests/test_gpu_qr.py.
+#ifdef NFM_EIG_TRIDIAG_V1 // measurement knob: the tridiagonalisation as it was before the fma form
+constexpr bool kTridiagFma = false;
+#else
+constexpr bool kTridiagFma = true;
+#endif
+
 template <typename T>
 struct FastSweeps {
     static constexpr bool on = true; // both dtypes; FAST (a template argument of the callers) selects it
@@ -173,6 +179,7 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
 #pragma unroll
     for (int i = 0; i < Dim<NT>::MAX; ++i)
         if (i < m) ss += x[i] * x[i];
+#ifdef NFM_EIG_TRIDIAG_V1
     if constexpr (FAST) {
         // eig_sym's fast arithmetic (policy above): |x| = ss * rsqrt(ss), u = x / |x| = x * rsqrt(ss2);
         // sums of squares outside the safe range (zero vectors, denormals, overflow) take the IEEE form
@@ -205,6 +212,38 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
             }
         return rho;
     }
+#else
+    if constexpr (FAST) {
+        // eig_sym's fast arithmetic (policy above): |x| = ss rsqrt(ss); the reflected component is
+        // x_b - rho = sgn(x_b) (|x_b| + |x|), so the squared norm of the un-normalised reflector is
+        // 2 |x| (|x| + |x_b|) -- two operations instead of a second sum of squares -- and
+        // u = x rsqrt(that).  Sums of squares outside the safe range (zero vectors, denormals,
+        // overflow, NaN) take the IEEE form on a uniform vote, as in givens_fast1.
+        T ssf = T(0);
+#pragma unroll
+        for (int i = 0; i < Dim<NT>::MAX; ++i)
+            if (i < m) ssf = fma_t(x[i], x[i], ssf);
+        const T nrm = ssf * rsq_nr(ssf);
+        const T ss2 = (nrm + fabs_(xb)) * (nrm + nrm);
+        const bool ok = ssf > FastRange<T>::lo && ssf < FastRange<T>::hi && ss2 < FastRange<T>::hi;
+        const T rhof = rho * nrm;
+        const T inv = rsq_nr(ss2);
+        if (__builtin_expect(__any(!ok), 0)) {
+            T y[Dim<NT>::MAX];
+#pragma unroll
+            for (int i = 0; i < Dim<NT>::MAX; ++i) y[i] = x[i];
+            const T rho2 = householder1<T, NT, false>(y, m, basis);
+#pragma unroll
+            for (int i = 0; i < Dim<NT>::MAX; ++i)
+                if (i < m) x[i] = ok ? ((i == basis) ? x[i] - rhof : x[i]) * inv : y[i];
+            return ok ? rhof : rho2;
+        }
+#pragma unroll
+        for (int i = 0; i < Dim<NT>::MAX; ++i)
+            if (i < m) x[i] = ((i == basis) ? x[i] - rhof : x[i]) * inv;
+        return rhof;
+    }
+#endif
     rho *= sqrt_(ss);
 #pragma unroll
     for (int i = 0; i < Dim<NT>::MAX; ++i)
@@ -297,6 +336,32 @@ __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MA
                 for (int r = 0; r < MX; ++r)
                     if (r < m) up[k][r] = u[r];
             }
+            if constexpr (FAST && kTridiagFma) {
+                // the same rank-2 update A -= u v^T + v u^T, v = 2 (A u - (u.Au) u), contracted to fma
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < m) {
+                        T y = T(0);
+#pragma unroll
+                        for (int j = 0; j < MX; ++j)
+                            if (j < m) y = fma_t(i >= j ? a[o + i][o + j] : a[o + j][o + i], u[j], y);
+                        v[i] = y;
+                    }
+                T d = T(0);
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < m) d = fma_t(u[i], v[i], d);
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < m) v[i] = fma_t(-u[i], d, v[i]) * T(2);
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < m) {
+#pragma unroll
+                        for (int j = 0; j <= i; ++j)
+                            a[o + i][o + j] = fma_t(-u[j], v[i], fma_t(-v[j], u[i], a[o + i][o + j]));
+                    }
+            } else {
 #pragma unroll
             for (int i = 0; i < MX; ++i)
                 if (i < m) {
@@ -322,6 +387,7 @@ __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MA
                         a[o + i][o + j] -= w;
                     }
                 }
+            }
             a[o][k] = alpha;
 #pragma unroll
             for (int r = k + 2; r < MX; ++r)
@@ -483,6 +549,43 @@ __device__ __forceinline__ void tri_sweep_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MA
     h[m - 2][m - 1] = e;
 }
 
+// The last stage of the deflation (m == 2) in the fast sweeps: the leading 2 x 2 block [a b; b d]
+// is diagonalised by ONE Jacobi rotation instead of being iterated on -- a lockstep wavefront pays
+// 3-4 shifted sweeps for its slowest lane there, a third of all the instructions of a 3 x 3 problem.
+//   delta = (d - a) / 2,  r = sqrt(delta^2 + b^2),  t = sgn(delta) b / (|delta| + r)   (|t| <= 1),
+//   a' = a - t b,  d' = d + t b;   (c, s) = (1, t) / sqrt(1 + t^2) rotates columns 0, 1 of U.
+// b == 0 gives t = +-0 and (c, s) = (1, 0) exactly: a diagonal block comes back bit for bit.
+// Lanes whose delta^2 + b^2 is outside the safe range of the hardware rsqrt (0, denormal, inf, NaN)
+// are left untouched and reported: they take the iterative path.
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ bool jacobi2_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                              int n)
+{
+    constexpr int MX = Dim<NT>::MAX;
+    const T a = h[0][0], d = h[1][1], b = h[1][0];
+    const T dl = (d - a) * T(0.5);
+    const T r2 = fma_t(dl, dl, b * b);
+    const bool ok = r2 > FastRange<T>::lo && r2 < FastRange<T>::hi;
+    const T den = fma_t(r2, rsq_nr(r2), fabs_(dl));
+    T inv = hw_rcp(den);
+    inv = fma_t(fma_t(-den, inv, T(1)), inv, inv);
+    const T t = ((dl < T(0)) ? -b : b) * inv;
+    h[0][0] = ok ? fma_t(-t, b, a) : a;
+    h[1][1] = ok ? fma_t(t, b, d) : d;
+    h[1][0] = ok ? T(0) : b;
+    h[0][1] = h[1][0];
+    if (WITH_U) {
+        T c = rsq_nr(fma_t(t, t, T(1)));
+        T s = t * c;
+        c = ok ? c : T(1);
+        s = ok ? s : T(0);
+#pragma unroll
+        for (int i = 0; i < MX; ++i)
+            if (i < n) rot_fast1(u[i][0], u[i][1], c, s);
+    }
+    return ok;
+}
+
 // _qr_explicit(_vectors)_jit_ :572-656 with sym = True; convergence per lane (Q9)
 template <typename T, int NT, bool WITH_U, bool FAST = false>
 __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
@@ -491,6 +594,17 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
     constexpr bool FM = FAST && FastSweeps<T>::on;
+    // The reference deflates when e^2 < tol (d0^2 + d1^2) with tol = 1e-32 by default: |e| < 1e-16 |d|,
+    // the working precision of float64 -- but eight orders below float32's, where it costs one more
+    // sweep per eigenvalue just to square an off-diagonal that is already below half an ulp.  The fast
+    // sweeps floor the tolerance at the working precision of the dtype, |e| <= eps/4 |d| (the neglected
+    // entry moves an eigenvalue by at most |e|: a quarter of an ulp); a larger caller tolerance is kept.
+    if constexpr (FM) {
+#ifndef NFM_EIG_TOL_V1
+        const double floor_ = sizeof(T) == 4 ? 0x1p-52 : 0x1p-110; // (eps / 4)^2, eps = 2^-24 / 2^-53
+        tol = tol > floor_ ? tol : floor_;
+#endif
+    }
     if (WITH_U) {
 #pragma unroll
         for (int i = 0; i < MX; ++i)
@@ -500,8 +614,13 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
 #pragma unroll
     for (int m = MX; m >= 2; --m) {
         if (m <= n) {
+            int iters = max_iter;
+            if constexpr (FM) {
+                if (m == 2 && max_iter > 0)
+                    if (jacobi2_fast1<T, NT, WITH_U>(h, u, n)) iters = 0;
+            }
             double sos_prev = 0.0;
-            for (int it = 0; it < max_iter; ++it) {
+            for (int it = 0; it < iters; ++it) {
                 T sigma;
                 if constexpr (FM) sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
                 else sigma = wilkinson1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
@@ -541,13 +660,28 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
 
 // apply P = I - 2 w w^T (w of length m, acting on the trailing m rows) from the left
 // householder_apply_ :72-106, side='left'
-template <typename T, int NT>
+template <typename T, int NT, bool FAST = false>
 __device__ __forceinline__ void reflect_left1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m,
                                               const T (&w)[Dim<NT>::MAX])
 {
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
     const int k0 = n - m;
+    if constexpr (FAST && kTridiagFma) { // eig_sym's fast arithmetic: the same update contracted to fma
+#pragma unroll
+        for (int c = 0; c < MX; ++c)
+            if (c < n) {
+                T d = T(0);
+#pragma unroll
+                for (int r = 0; r < MX; ++r)
+                    if (r >= k0 && r < n) d = fma_t(w[r - k0 < 0 ? 0 : r - k0], a[r][c], d);
+                d += d;
+#pragma unroll
+                for (int r = 0; r < MX; ++r)
+                    if (r >= k0 && r < n) a[r][c] = fma_t(-w[r - k0 < 0 ? 0 : r - k0], d, a[r][c]);
+            }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < MX; ++c)
         if (c < n) {
@@ -579,7 +713,7 @@ __device__ __forceinline__ void eig_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (
                 T w[MX];
 #pragma unroll
                 for (int r = 0; r < MX; ++r) w[r] = up[k][r];
-                reflect_left1<T, NT>(u, n, n - k - 1, w);
+                reflect_left1<T, NT, FAST && FastSweeps<T>::on>(u, n, n - k - 1, w);
             }
     }
 }
