@@ -60,12 +60,6 @@ __device__ __forceinline__ bool finite_(T x)
 // 1.4e-6.  So the reference-order arithmetic stays available (FM = false: bit-identical to the
 // CPU restatement, same order, same signs) and the caller picks: `eig_sym(..., arithmetic=)`.
 // Error model and its tests: tests/test_gpu_qr.py.
-#ifdef NFM_EIG_TRIDIAG_V1 // measurement knob: the tridiagonalisation as it was before the fma form
-constexpr bool kTridiagFma = false;
-#else
-constexpr bool kTridiagFma = true;
-#endif
-
 template <typename T>
 struct FastSweeps {
     static constexpr bool on = true; // both dtypes; FAST (a template argument of the callers) selects it
@@ -122,7 +116,8 @@ __device__ __forceinline__ void givens_fast1(T x, T y, T &c, T &s)
     // lanes that need the IEEE form: squared norm outside the safe range, or an axis-aligned pair
     // (x y == 0) -- that one is an exact rotation in the reference (x / |x| = +-1) and must stay
     // exact, so that diagonal / already deflated input comes back bit for bit
-    const bool ok = r2 > FastRange<T>::lo && r2 < FastRange<T>::hi && x * y != T(0);
+    // |x y| <= r2 / 2: a product above the floor bounds r2 from below as well
+    const bool ok = fabs_(x * y) > FastRange<T>::lo && r2 < FastRange<T>::hi;
     const T inv = rsq_nr(r2);
     c = x * inv;
     s = -(y * inv);
@@ -179,40 +174,6 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
 #pragma unroll
     for (int i = 0; i < Dim<NT>::MAX; ++i)
         if (i < m) ss += x[i] * x[i];
-#ifdef NFM_EIG_TRIDIAG_V1
-    if constexpr (FAST) {
-        // eig_sym's fast arithmetic (policy above): |x| = ss * rsqrt(ss), u = x / |x| = x * rsqrt(ss2);
-        // sums of squares outside the safe range (zero vectors, denormals, overflow) take the IEEE form
-        // (uniform votes, as in givens_fast1)
-        const bool ok1 = ss > FastRange<T>::lo && ss < FastRange<T>::hi;
-        T nrm1 = ss * rsq_nr(ss);
-        if (__builtin_expect(__any(!ok1), 0)) {
-            const T e = sqrt_(ss);
-            nrm1 = ok1 ? nrm1 : e;
-        }
-        rho *= nrm1;
-#pragma unroll
-        for (int i = 0; i < Dim<NT>::MAX; ++i)
-            if (i < m) x[i] = (i == basis) ? x[i] - rho : x[i];
-        T ss2 = T(0);
-#pragma unroll
-        for (int i = 0; i < Dim<NT>::MAX; ++i)
-            if (i < m) ss2 += x[i] * x[i];
-        const bool ok2 = ss2 > FastRange<T>::lo && ss2 < FastRange<T>::hi;
-        T inv = rsq_nr(ss2);
-        if (__builtin_expect(__any(!ok2), 0)) {
-            const T e = T(1) / sqrt_(ss2);
-            inv = ok2 ? inv : e;
-        }
-#pragma unroll
-        for (int i = 0; i < Dim<NT>::MAX; ++i)
-            if (i < m) {
-                const T v = x[i] * inv;
-                x[i] = finite_(v) ? v : T(0);
-            }
-        return rho;
-    }
-#else
     if constexpr (FAST) {
         // eig_sym's fast arithmetic (policy above): |x| = ss rsqrt(ss); the reflected component is
         // x_b - rho = sgn(x_b) (|x_b| + |x|), so the squared norm of the un-normalised reflector is
@@ -243,7 +204,6 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
             if (i < m) x[i] = ((i == basis) ? x[i] - rhof : x[i]) * inv;
         return rhof;
     }
-#endif
     rho *= sqrt_(ss);
 #pragma unroll
     for (int i = 0; i < Dim<NT>::MAX; ++i)
@@ -336,7 +296,7 @@ __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MA
                 for (int r = 0; r < MX; ++r)
                     if (r < m) up[k][r] = u[r];
             }
-            if constexpr (FAST && kTridiagFma) {
+            if constexpr (FAST) {
                 // the same rank-2 update A -= u v^T + v u^T, v = 2 (A u - (u.Au) u), contracted to fma
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
@@ -600,11 +560,10 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
     // sweeps floor the tolerance at the working precision of the dtype, |e| <= eps/4 |d| (the neglected
     // entry moves an eigenvalue by at most |e|: a quarter of an ulp); a larger caller tolerance is kept.
     if constexpr (FM) {
-#ifndef NFM_EIG_TOL_V1
         const double floor_ = sizeof(T) == 4 ? 0x1p-52 : 0x1p-110; // (eps / 4)^2, eps = 2^-24 / 2^-53
         tol = tol > floor_ ? tol : floor_;
-#endif
     }
+    const T tol_t = (T)tol, stuck_t = (T)(tol * 1e-3);
     if (WITH_U) {
 #pragma unroll
         for (int i = 0; i < MX; ++i)
@@ -620,6 +579,7 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                     if (jacobi2_fast1<T, NT, WITH_U>(h, u, n)) iters = 0;
             }
             double sos_prev = 0.0;
+            T ratio_prev = T(0);
             for (int it = 0; it < iters; ++it) {
                 T sigma;
                 if constexpr (FM) sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
@@ -638,12 +598,20 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                 // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
                 // more: a zero off-diagonal (diagonal or zero blocks, padding lanes of the last
                 // tile) or NaNs would otherwise spin through all max_iter identical iterations
-                if ((double)sos_lower <= tol * (double)sos_diag || sos_lower != sos_lower) {
+                bool conv;
+                if constexpr (FM) conv = sos_lower <= tol_t * sos_diag; // in T: tol_t >= (eps/4)^2 is a normal number
+                else conv = (double)sos_lower <= tol * (double)sos_diag;
+                if (conv || sos_lower != sos_lower) {
 #pragma unroll
                     for (int j = 0; j < m - 1; ++j) h[m - 1][j] = T(0);
                     break;
                 }
-                if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
+                if constexpr (FM && !WITH_U) { // the same exit in T (the ratio only detects a fixed point)
+                    const T ratio = sos_lower * hw_rcp(sos_diag);
+                    const T dif = fabs_(ratio_prev - ratio);
+                    if (ratio_prev != T(0) && dif < stuck_t * ratio_prev) break;
+                    ratio_prev = ratio;
+                } else if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
                     // |prev - new| / prev < tol * 1e-3, written without the fp64 division (prev > 0)
                     double sos_new;
                     if constexpr (FM) // the ratio only detects a fixed point of the iteration
@@ -667,7 +635,7 @@ __device__ __forceinline__ void reflect_left1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX]
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
     const int k0 = n - m;
-    if constexpr (FAST && kTridiagFma) { // eig_sym's fast arithmetic: the same update contracted to fma
+    if constexpr (FAST) { // eig_sym's fast arithmetic: the same update contracted to fma
 #pragma unroll
         for (int c = 0; c < MX; ++c)
             if (c < n) {

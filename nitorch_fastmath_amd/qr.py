@@ -17,11 +17,14 @@ own deflation order, i.e. what upstream returns when called on that matrix alone
 for a batch depends on the other matrices in the batch).
 
 `eig_sym` has two arithmetic modes (`arithmetic=`, default `SWEEP_ARITHMETIC`):
-`'fast'` runs the QR sweeps on v_rsq + Newton steps with fma contraction (2x the throughput,
-the same accuracy against the exact eigenvalues, but the deflation ORDER and the eigenvector
-SIGNS -- both unspecified upstream -- can differ from the reference's);
-`'reference'` keeps the reference's operation order with IEEE division and square root and
-reproduces the CPU path bit for bit.
+`'fast'` runs the QR sweeps on v_rsq + Newton steps with fma contraction, diagonalises the last
+2x2 block in closed form (one Jacobi rotation) and never deflates below the working precision
+of the dtype (`tol` is floored at (eps/4)^2: float32 stops at |e| <= 1.5e-8 |d| where the
+reference's default 1e-32 asks for 1e-16 |d|) -- 3-4x the throughput, the same accuracy
+against the exact eigenvalues, but the deflation ORDER and the eigenvector SIGNS -- both
+unspecified upstream -- can differ from the reference's;
+`'reference'` keeps the reference's operation order, tolerance and IEEE division / square root
+and reproduces the CPU path bit for bit.
 """
 __all__ = [
     'eig_sym',
@@ -111,6 +114,7 @@ def eig_sym(a, compute_u=False, upper=True, inplace=False, check_finite=True, ma
     check_finite : `bool`, default=True
     max_iter : `int`, default=1024
     tol : `float`, default=1e-32
+        deflate when e^2 <= tol (d0^2 + d1^2); `arithmetic='fast'` uses max(tol, (eps/4)^2)
     arithmetic : `{'fast', 'reference'}`, keyword-only, default=`SWEEP_ARITHMETIC`
         extension, see the module docstring: `'reference'` reproduces the reference CPU path bit
         for bit (deflation order and eigenvector signs included).

@@ -284,3 +284,81 @@ def test_eig_sym_nothing_left_to_iterate(dev, oracle):
             e1.synchronize()
             best = min(best, e0.elapsed_time(e1))
         assert best < 0.5, f'eig_sym on a ragged batch took {best:.3f} ms'
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_eig_sym_fast_last_stage_closed_form(dev, dn):
+    """the fast sweeps diagonalise the last 2x2 block by one Jacobi rotation (nfm_qr_core.hpp,
+    jacobi2_fast1): eigenpairs of 2x2 problems -- random, diagonal (exact), equal diagonal, graded,
+    and magnitudes outside the safe range of the hardware rsqrt (those lanes iterate instead)"""
+    dtype = torch.float32 if dn == 'f32' else torch.float64
+    eps = EPS[dn]
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(4099, 2, 2, generator=g, dtype=torch.float64)
+    a = a + a.transpose(-1, -2)
+    a[0] = torch.tensor([[3.0, 0.0], [0.0, -1.0]])                    # diagonal: comes back bit for bit
+    a[1] = torch.tensor([[2.0, 5.0], [5.0, 2.0]])                     # delta = 0: t = +-1
+    a[2] = torch.tensor([[1.0, 1e-9], [1e-9, -1.0]])                  # tiny coupling
+    a[3] = torch.tensor([[1e-3, 1.0], [1.0, -1e-3]])                  # coupling dominates
+    a[4] = torch.zeros(2, 2)
+    big, small = (1e18, 1e-18) if dn == 'f32' else (1e140, 1e-140)
+    a[5] = torch.tensor([[1.0, 2.0], [2.0, -3.0]], dtype=torch.float64) * big              # delta^2 + b^2 overflows the safe range
+    a[6] = torch.tensor([[1.0, 2.0], [2.0, -3.0]], dtype=torch.float64) * small            # ... and underflows it
+    ad = a.to(dtype).to(dev)
+    v, u = Q().eig_sym(ad, compute_u=True)
+    v0 = Q().eig_sym(ad)
+    assert torch.equal(v, v0)
+    a64 = ad.double().cpu()
+    truth = torch.linalg.eigvalsh(a64)
+    got = v.double().cpu().sort(-1).values
+    scale = a64.abs().amax((-1, -2)).clamp_min(1e-300)
+    assert ((got - truth).abs().amax(-1) / scale).max().item() <= 4 * eps
+    # eigenpairs: A u = u diag(v), u orthogonal
+    ud, vd = u.double().cpu(), v.double().cpu()
+    res = (a64 @ ud - ud * vd[:, None, :]).abs().amax((-1, -2)) / scale
+    assert res.max().item() <= 8 * eps
+    assert (ud.transpose(-1, -2) @ ud - torch.eye(2, dtype=torch.float64)).abs().max().item() <= 8 * eps
+    assert sorted(v[0].tolist()) == [-1.0, 3.0] and torch.equal(u[0].abs(), torch.eye(2, dtype=dtype, device=dev))
+    assert torch.equal(v[4], torch.zeros(2, dtype=dtype, device=dev))
+    # the same stage closes larger problems: bit-identical to itself run twice, and max_iter = 0
+    # still means "no iteration at all" (the diagonal of the tridiagonal form, as upstream)
+    b = torch.randn(1000, 4, 4, generator=g, dtype=torch.float64)
+    b = (b + b.transpose(-1, -2)).to(dtype).to(dev)
+    tri = Q().hessenberg_sym(b)
+    none = n_(Q().eig_sym(b, max_iter=0))
+    # (a reflector is ill-determined where the column below the diagonal is small, so two roundings of
+    # the tridiagonalisation agree only loosely entry by entry)
+    assert relerr(none, n_(tri.diagonal(0, -1, -2))) <= 1e4 * eps
+    assert relerr(none, n_(Q().eig_sym(b))) > 1e-2
+
+
+@pytest.mark.parametrize('n', [3, 4, 6, 8])
+def test_eig_sym_fast_tolerance_floor(dev, oracle, n):
+    """float32 fast sweeps stop deflating at |e| <= eps/4 |d| (upstream's default 1e-32 asks for
+    1e-16 |d|): the eigenvalues stay as close to the float64 truth as the reference-order ones, a
+    larger caller tolerance is honoured, and float64 (where 1e-32 IS the working precision) is
+    untouched"""
+    rng = np.random.default_rng(70 + n)
+    a = rng.standard_normal((20000, n, n))
+    a = (a + a.swapaxes(-1, -2)).astype(np.float32)
+    truth = np.linalg.eigvalsh(a.astype(np.float64))
+    scale = np.abs(truth).max(-1, keepdims=True)
+    ref = np.sort(oracle.eig_sym(a), -1)
+    fast = np.sort(n_(Q().eig_sym(t(a, dev))), -1)
+    err_ref = (np.abs(ref - truth) / scale).max()
+    err_fast = (np.abs(fast - truth) / scale).max()
+    assert err_fast <= 2 * err_ref + 4 * n * EPS['f32'], (err_fast, err_ref)
+    # mean error too: the floor must not shift the bulk, not only the worst case
+    assert (np.abs(fast - truth) / scale).mean() <= 1.5 * (np.abs(ref - truth) / scale).mean()
+    # a loose caller tolerance is kept (errors of its size appear), a tight one is floored
+    loose = np.sort(n_(Q().eig_sym(t(a, dev), tol=1e-4)), -1)
+    err_loose = (np.abs(loose - truth) / scale).max()
+    assert 4 * err_fast < err_loose < 2e-2
+    tight = n_(Q().eig_sym(t(a, dev), tol=0.0))
+    assert np.array_equal(np.sort(tight, -1), fast)
+    # float64: the default tolerance is above the floor -> same iterates as before the floor existed
+    a64 = a[:2000].astype(np.float64)
+    f64 = n_(Q().eig_sym(t(a64, dev)))
+    assert np.array_equal(f64, n_(Q().eig_sym(t(a64, dev), tol=1e-32)))
+    t64 = np.linalg.eigvalsh(a64)
+    assert (np.abs(np.sort(f64, -1) - t64) / np.abs(t64).max(-1, keepdims=True)).max() <= 8 * n * EPS['f64']
