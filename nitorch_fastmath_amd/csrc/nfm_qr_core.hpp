@@ -448,7 +448,7 @@ __device__ __forceinline__ T wilkinson_fast1(T h0, T h1, T b)
     const T sb2 = (d < T(0)) ? -b2 : b2;
     const T t = fma_t(d, d, b2);
     const bool ok = t > FastRange<T>::lo && t < FastRange<T>::hi;
-    T sigma = h1 - sb2 * hw_rcp(fabs_(d) + hw_sqrt(t));
+    T sigma = fma_t(-sb2, hw_rcp(fabs_(d) + hw_sqrt(t)), h1); // (explicit: the packed twin must contract the same way)
     if (__builtin_expect(__any(!ok), 0)) {
         const T s2 = wilkinson1<T>(h0, h1, b);
         sigma = ok ? sigma : s2;
