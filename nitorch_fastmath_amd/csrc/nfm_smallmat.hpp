@@ -169,35 +169,64 @@ __device__ __forceinline__ void sym_cof3(const T *d, const T *u, T (&co)[6])
     co[5] = u[0] * u[1] - d[0] * u[2];
 }
 
-// x = A^-1 v, compact A of order M <= 4, _impl/sym.py:193-200, 212-226, 251-324, 384-391
+// x = A^-1 v, compact A of order M <= 4, _impl/sym.py:193-200, 212-226, 251-324, 384-391.
+// Two halves, so that one matrix solved against many vectors derives its cofactors once
+// (sym_solve_bcast_kernel, nfm_sym.hip): the part that depends on the matrix only ...
+template <int M>
+struct SymCofLen {
+    static constexpr int value = M == 4 ? 10 : (M == 3 ? 6 : (M == 2 ? 3 : 1));
+};
 template <typename T, int M>
-__device__ __forceinline__ void sym_solve_closed(const T (&m)[sym_k(M)], const T (&v)[M], T (&r)[M])
+__device__ __forceinline__ void sym_solve_prepare(const T (&m)[sym_k(M)], T (&co)[SymCofLen<M>::value], T &det)
 {
 #pragma clang fp contract(off)
     static_assert(M >= 1 && M <= 4, "closed forms exist for M <= 4");
     if constexpr (M == 1) {
-        r[0] = v[0] / m[0];
+        co[0] = T(1);
+        det = m[0];
     } else if constexpr (M == 2) {
-        T det = sym_det2(&m[0], &m[2]);
-        r[0] = (m[1] * v[0] - m[2] * v[1]) / det;
-        r[1] = (m[0] * v[1] - m[2] * v[0]) / det;
+        det = sym_det2(&m[0], &m[2]);
+        co[0] = m[0];
+        co[1] = m[1];
+        co[2] = m[2];
     } else if constexpr (M == 3) {
-        T det = sym_det3(&m[0], &m[3]);
-        T co[6];
+        det = sym_det3(&m[0], &m[3]);
         sym_cof3(&m[0], &m[3], co);
+    } else {
+        det = sym_det4(&m[0], &m[4]);
+        sym_cof4(&m[0], &m[4], co);
+    }
+}
+
+// ... and the part per right-hand side
+template <typename T, int M>
+__device__ __forceinline__ void sym_solve_apply(const T (&co)[SymCofLen<M>::value], T det, const T (&v)[M], T (&r)[M])
+{
+#pragma clang fp contract(off)
+    if constexpr (M == 1) {
+        r[0] = v[0] / det;
+    } else if constexpr (M == 2) {
+        r[0] = (co[1] * v[0] - co[2] * v[1]) / det;
+        r[1] = (co[0] * v[1] - co[2] * v[0]) / det;
+    } else if constexpr (M == 3) {
         r[0] = ((co[0] * v[0] + co[3] * v[1]) + co[4] * v[2]) / det;
         r[1] = ((co[3] * v[0] + co[1] * v[1]) + co[5] * v[2]) / det;
         r[2] = ((co[4] * v[0] + co[5] * v[1]) + co[2] * v[2]) / det;
     } else {
-        T det = sym_det4(&m[0], &m[4]);
-        T co[10];
-        sym_cof4(&m[0], &m[4], co);
         // res[i] = cof_ii * v[i]; res[i] += inv.. * v[..] in the reference's order
         r[0] = (((co[0] * v[0] + co[4] * v[1]) + co[5] * v[2]) + co[6] * v[3]) / det;
         r[1] = (((co[1] * v[1] + co[4] * v[0]) + co[7] * v[2]) + co[8] * v[3]) / det;
         r[2] = (((co[2] * v[2] + co[5] * v[0]) + co[7] * v[1]) + co[9] * v[3]) / det;
         r[3] = (((co[3] * v[3] + co[6] * v[0]) + co[8] * v[1]) + co[9] * v[2]) / det;
     }
+}
+
+template <typename T, int M>
+__device__ __forceinline__ void sym_solve_closed(const T (&m)[sym_k(M)], const T (&v)[M], T (&r)[M])
+{
+    T co[SymCofLen<M>::value], det;
+    sym_solve_prepare<T, M>(m, co, det);
+    sym_solve_apply<T, M>(co, det, v, r);
 }
 
 // compact inverse, order M <= 4: what `sym_invert` (_impl/sym.py:455-493) obtains by

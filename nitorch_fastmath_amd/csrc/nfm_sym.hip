@@ -29,10 +29,68 @@ namespace nfm {
         return NFM_ESIZE;                \
     }
 
+// One matrix (per outer slab) solved against many vectors, closed forms (M <= 4): the cofactors and
+// the determinant are derived once per lane and applied to V right-hand sides -- the same operations
+// in the same order as SolveOp (sym_solve_prepare / sym_solve_apply are the two halves of
+// sym_solve_closed), so the results are bit for bit the per-record kernel's, at 16 multiply-adds and
+// 4 divisions per system instead of ~250 instructions: the kernel becomes a stream over the vectors.
+template <typename T, int M, int V>
+__global__ __launch_bounds__(256) void sym_solve_bcast_kernel(Opnd mat, Opnd vec, Opnd out, int64_t n_inner,
+                                                              SolveParams p)
+{
+    constexpr int K = sym_k(M);
+    using RV = Rec<1, M>;
+    const int64_t o = blockIdx.y;
+    const T *pm = reinterpret_cast<const T *>(mat.ptr) + o * mat.so;
+    T a[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) a[c] = pm[c * mat.sc];
+    if (p.has_eps) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) a[i] += (T)p.eps[i];
+    }
+    T co[SymCofLen<M>::value], det;
+    sym_solve_prepare<T, M>(a, co, det);
+    const int64_t base = (int64_t)blockIdx.x * (256 * V) + threadIdx.x;
+    T v[V][M];
+#pragma unroll
+    for (int q = 0; q < V; ++q) rec_direct_load<T, RV>(vec, vec.tiled, o, base + q * 256, base + q * 256 < n_inner, v[q]);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        T r[M];
+        sym_solve_apply<T, M>(co, det, v[q], r);
+        rec_direct_store<T, RV>(out, out.tiled, o, base + q * 256, base + q * 256 < n_inner, r);
+    }
+}
+
+template <typename T, int M>
+static int sym_solve_bcast(int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
+                           const nfm_operand *out, const SolveParams &p, void *stream)
+{
+    constexpr int V = 4;
+    const int64_t nblk = (ni + 256 * V - 1) / (256 * V);
+    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    auto mode = [](const nfm_operand *op) {
+        return packed_ok(op, M, 1, M, sizeof(T)) ? (int)MODE_PACKED : (int)MODE_STRIDED;
+    };
+    hipLaunchKernelGGL((sym_solve_bcast_kernel<T, M, V>), dim3((unsigned)nblk, (unsigned)no, 1), dim3(256, 1, 1), 0,
+                       static_cast<hipStream_t>(stream), make_opnd(mat, MODE_STRIDED), make_opnd(vec, mode(vec)),
+                       make_opnd(out, mode(out)), ni, p);
+    return launch_status();
+}
+
 template <typename T>
 static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
                        const nfm_operand *out, const SolveParams &p, void *stream)
 {
+    // a matrix that is the same along the inner batch level (stride 0: one Hessian, many gradients)
+    if (kind == NFM_MAT_SYM && M >= 2 && M <= 4 && mat->stride_inner == 0 && ni >= 1024) {
+        switch (M) {
+        case 2: return sym_solve_bcast<T, 2>(no, ni, mat, vec, out, p, stream);
+        case 3: return sym_solve_bcast<T, 3>(no, ni, mat, vec, out, p, stream);
+        default: return sym_solve_bcast<T, 4>(no, ni, mat, vec, out, p, stream);
+        }
+    }
     if (M > 8) {
         if (kind == NFM_MAT_SYM && no == 1) { // contiguous operands: registers; else LDS-resident
             if (rowwave_first<T>(M, RWW_SOLVE)) { // one matrix per 16 lanes (nfm_rowwave.hip)

@@ -396,3 +396,39 @@ def test_fused_matmul_solve_equals_the_chain(dev, oracle, dn):
     jr = torch.randn(9, 3, 3, device=dev, dtype=torch.float64, requires_grad=True)
     S.sym_matmul_solve(jr, t(spd_np(9, 3, np.float64, 2)[0], dev), torch.randn(9, 3, device=dev, dtype=torch.float64)).sum().backward()
     assert jr.grad is not None and bool(torch.isfinite(jr.grad).all())
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [2, 3, 4])
+def test_one_matrix_many_vectors(dev, oracle, dn, M):
+    """a matrix that is the same along the inner batch level (stride 0) takes sym_solve_bcast_kernel:
+    cofactors once per lane, V right-hand sides each -- the same operations in the same order as the
+    per-record kernel, so still bit-identical to the oracle (closed forms)"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    K = M * (M + 1) // 2
+    B, n = 3, 4 * 1024 + 37                        # ragged tail, several workgroups
+    mat, _ = spd_np(B, M, dtype, 50 + M)
+    vec = np.random.default_rng(60 + M).standard_normal((B, n, M)).astype(dtype)
+    S = N().sym
+    md, vd = t(mat, dev), t(vec, dev)
+    full = np.broadcast_to(mat[:, None, :], (B, n, K))
+    ref = oracle.sym_solve(np.ascontiguousarray(full).reshape(-1, K), vec.reshape(-1, M)).reshape(B, n, M)
+    check(S.sym_solve(md[0], vd[0]), ref[0], dn, True)                       # (K,) against (n, M)
+    check(S.sym_solve(md[:, None, :], vd), ref, dn, True)                    # (B, 1, K) against (B, n, M)
+    check(S.sym_solve(md[1], vd[1, ::2]), ref[1, ::2], dn, True)             # strided vectors
+    # a materialised copy of the same matrix goes through the per-record kernel: same bits
+    check(S.sym_solve(md[0].expand(n, K).contiguous(), vd[0]), ref[0], dn, True)
+    # out= into a padded buffer, in place, and eps on the diagonal
+    buf = torch.full((n, M + 1), 7.0, dtype=md.dtype, device=dev)
+    S.sym_solve(md[2], vd[2], out=buf[:, :M])
+    check(buf[:, :M], ref[2], dn, True)
+    assert bool((buf[:, M] == 7).all())
+    v = vd[0].clone()
+    S.sym_solve_(md[0], v)
+    check(v, ref[0], dn, True)
+    eps = [0.5, 0.25]
+    e = np.array((eps + [eps[-1]] * M)[:M], dtype)
+    mat_e = mat.copy()
+    mat_e[:, :M] += e
+    ref_e = oracle.sym_solve(np.ascontiguousarray(np.broadcast_to(mat_e[0], (n, K))), vec[0])
+    check(S.sym_solve(md[0], vd[0], eps=eps), ref_e, dn, True)
