@@ -9,17 +9,20 @@
 //
 // A float is mapped to an unsigned key that sorts like the float (sign bit flipped for positives,
 // all bits flipped for negatives; NaN -> the largest key, so NaNs sort last and are never selected
-// when omitted), and the key of rank k is found digit by digit, 8 bits at a time from the top:
+// when omitted), and the key of rank k is found digit by digit from the top (8 bits at a time where
+// the row sits in registers, 11 where every digit is a pass over HBM):
 // count the elements per digit value among those that match the digits chosen so far, keep the
-// digit whose cumulative count passes k.  4 passes for float32, 8 for float64, no data movement.
+// digit whose cumulative count passes k.  No data movement.
 //
 //   red <= 32:   8 / 16 / 32 lanes per row, one element per lane, ranks counted directly;
 //   red <= 1024: one WAVEFRONT per row, the row in registers (<= 16 keys per lane), a 256-bin LDS
 //                histogram per wavefront, ds_add for the counts, a 64-lane scan to pick the digit;
 //   longer rows: every pass streams the row once with 16-byte loads -- a grid of (chunks, rows)
-//                workgroups histograms into LDS and adds its 256 counts to the row's global
-//                histogram; a one-wavefront kernel per row picks the digit between passes.  A full
-//                reduction of 2^33 elements is 4 passes at the streaming rate.
+//                workgroups histograms into LDS and adds its counts to the row's global histogram;
+//                a one-wavefront kernel per row picks the digit between passes.  Here a pass costs
+//                a trip over HBM, so the digits are 11 bits wide (2048 bins, 8 KiB of LDS): 3 passes
+//                for float32 (11 + 11 + 10 bits), 6 for float64 -- a full reduction of 2^33
+//                elements is 3 passes at the streaming rate.
 #include "nfm_reduce_common.hpp"
 
 namespace nfm {
@@ -241,7 +244,49 @@ __global__ __launch_bounds__(256) void median_tiny_kernel(const T *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// long rows: per-row state in the workspace
+// long rows: 11-bit digits.  Pass p (0 = most significant) covers key bits [shift, shift + width).
+constexpr int kLongBits = 11, kLongBins = 1 << kLongBits;
+template <typename T>
+struct LongDigits {
+    static constexpr int bits = 8 * (int)sizeof(T);
+    static constexpr int passes = (bits + kLongBits - 1) / kLongBits;
+    static __host__ __device__ constexpr int width(int p) { return p + 1 < passes ? kLongBits : bits - kLongBits * (passes - 1); }
+    static __host__ __device__ constexpr int shift(int p) { return p + 1 < passes ? bits - kLongBits * (p + 1) : 0; }
+};
+
+// pick_digit for NB consecutive bins per lane (64 * NB bins)
+template <int NB>
+__device__ __forceinline__ unsigned pick_digit_n(const unsigned (&cnt)[NB], unsigned long long &k)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned tot, mine = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mine += cnt[b];
+    const unsigned before = wave_excl_scan(mine, tot);
+    const bool here = (unsigned long long)before <= k && k < (unsigned long long)before + mine;
+    const unsigned long long m = __ballot(here);
+    const int src = m ? __builtin_ctzll(m) : 63; // k < total always: exactly one lane
+    unsigned digit = 0;
+    unsigned long long kk = k;
+    if (lane == src) {
+        unsigned long long r = k - before;
+        unsigned d = 0;
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b)
+            if (d == (unsigned)b && r >= cnt[b]) {
+                r -= cnt[b];
+                d = b + 1;
+            }
+        digit = NB * lane + d;
+        kk = r;
+    }
+    digit = __shfl(digit, src, 64);
+    const unsigned lo = __shfl((unsigned)kk, src, 64), hi = __shfl((unsigned)(kk >> 32), src, 64);
+    k = ((unsigned long long)hi << 32) | lo;
+    return digit;
+}
+
+// per-row state in the workspace
 struct RowState {
     unsigned long long prefix; // digits chosen so far
     unsigned long long k;      // rank still to resolve inside the prefix
@@ -253,31 +298,35 @@ struct RowState {
 static_assert(sizeof(RowState) == 40, "workspace layout");
 
 template <typename T>
-__global__ __launch_bounds__(256) void median_hist_kernel(const T *__restrict__ x, int64_t red, int64_t chunk, int d,
+__global__ __launch_bounds__(256) void median_hist_kernel(const T *__restrict__ x, int64_t red, int64_t chunk, int pass,
                                                           const RowState *__restrict__ st, unsigned *__restrict__ ghist,
                                                           unsigned long long *__restrict__ gnan)
 {
     using K = Key<T>;
     using U = typename K::U;
+    using D = LongDigits<T>;
     using V = typename VecOf<T>::gtype;
     constexpr int NV = VecOf<T>::N;
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[kLongBins];
     __shared__ unsigned nan_s;
     const int64_t row = blockIdx.y;
-    if (d != K::digits - 1 && st[row].want_nan) return;
-    hist[threadIdx.x] = 0;
+    const bool first_pass = pass == 0;
+    if (!first_pass && st[row].want_nan) return;
+#pragma unroll
+    for (int b = 0; b < kLongBins / 256; ++b) hist[threadIdx.x + 256 * b] = 0;
     if (threadIdx.x == 0) nan_s = 0;
     __syncthreads();
-    const bool first_pass = d == K::digits - 1;
     const U prefix = first_pass ? U(0) : (U)st[row].prefix;
-    const int shift = 8 * d;
+    const int shift = D::shift(pass), width = D::width(pass);
+    const int up = first_pass ? 0 : shift + width; // bits above this digit: chosen already (never the full width)
+    const unsigned mask = (1u << width) - 1u;
     const T *p = x + row * red;
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < red ? lo + chunk : red;
     unsigned nan = 0;
     auto take = [&](T v) {
         const U key = K::of(v);
         if (first_pass) nan += (v != v) ? 1u : 0u;
-        if (above(key, d, K::digits) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        if (first_pass || (U)(key >> up) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & mask], 1u);
     };
     // 16-byte loads over the aligned middle of the chunk, elements at its ragged ends
     int64_t j = lo + threadIdx.x;
@@ -298,23 +347,28 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const T *__restrict__ 
         if ((threadIdx.x & 63) == 0 && nan) atomicAdd(&nan_s, nan);
     }
     __syncthreads();
-    const unsigned c = hist[threadIdx.x];
-    if (c) atomicAdd(&ghist[row * 256 + threadIdx.x], c);
+#pragma unroll
+    for (int b = 0; b < kLongBins / 256; ++b) {
+        const unsigned c = hist[threadIdx.x + 256 * b];
+        if (c) atomicAdd(&ghist[row * kLongBins + threadIdx.x + 256 * b], c);
+    }
     if (first_pass && threadIdx.x == 0 && nan_s) atomicAdd(&gnan[row], (unsigned long long)nan_s);
 }
 
 // one wavefront per row: choose the digit of this pass, clear the histogram for the next one
 template <typename T>
-__global__ __launch_bounds__(64) void median_pick_kernel(int64_t red, int d, int omitnan, RowState *__restrict__ st,
+__global__ __launch_bounds__(64) void median_pick_kernel(int64_t red, int pass, int omitnan, RowState *__restrict__ st,
                                                          unsigned *__restrict__ ghist,
                                                          unsigned long long *__restrict__ gnan, T *__restrict__ val)
 {
     using K = Key<T>;
     using U = typename K::U;
+    using D = LongDigits<T>;
+    constexpr int NB = kLongBins / 64;
     const int64_t row = blockIdx.x;
     const int lane = threadIdx.x;
     RowState s = st[row];
-    if (d == K::digits - 1) {
+    if (pass == 0) {
         s.prefix = 0;
         s.nan = gnan[row];
         const unsigned long long count = omitnan ? (unsigned long long)red - s.nan : (unsigned long long)red;
@@ -322,22 +376,23 @@ __global__ __launch_bounds__(64) void median_pick_kernel(int64_t red, int d, int
         s.k = count ? (count - 1) / 2 : 0;
         s.first = red; // "not found yet" for the index pass
     }
+    unsigned *gh = ghist + row * kLongBins + NB * lane;
     if (!s.want_nan) {
-        unsigned cnt[4];
+        unsigned cnt[NB];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) cnt[b] = ghist[row * 256 + 4 * lane + b];
+        for (int b = 0; b < NB; ++b) cnt[b] = gh[b];
         unsigned long long k = s.k;
-        const unsigned digit = pick_digit(cnt, k);
+        const unsigned digit = pick_digit_n<NB>(cnt, k);
         s.k = k;
-        s.prefix = (s.prefix << 8) | digit;
+        s.prefix = (s.prefix << D::width(pass)) | digit;
     } else {
         s.prefix = ~0ull;
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) ghist[row * 256 + 4 * lane + b] = 0;
+    for (int b = 0; b < NB; ++b) gh[b] = 0;
     if (lane == 0) {
         st[row] = s;
-        if (d == 0) val[row] = s.want_nan ? (T)__builtin_nanf("") : K::back((U)s.prefix);
+        if (pass == D::passes - 1) val[row] = s.want_nan ? (T)__builtin_nanf("") : K::back((U)s.prefix);
     }
 }
 
@@ -418,7 +473,7 @@ static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, 
         return launch_status();
     }
     if (rows > 65535) return NFM_ESIZE; // grid.y; the facade splits (long rows are few)
-    const size_t need = (size_t)rows * (sizeof(RowState) + 256 * sizeof(unsigned) + sizeof(unsigned long long));
+    const size_t need = (size_t)rows * (sizeof(RowState) + kLongBins * sizeof(unsigned) + sizeof(unsigned long long));
     if (ws == nullptr || ws_bytes < need) return NFM_EINVAL;
     RowState *st = static_cast<RowState *>(ws);
     unsigned long long *gnan = reinterpret_cast<unsigned long long *>(st + rows);
@@ -428,11 +483,11 @@ static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, 
     const int64_t chunk = chunk_of(rows, red);
     const int64_t nch = (red + chunk - 1) / chunk;
     if (nch > 0x7fffffffLL) return NFM_ESIZE;
-    for (int d = Key<T>::digits - 1; d >= 0; --d) {
+    for (int pass = 0; pass < LongDigits<T>::passes; ++pass) {
         hipLaunchKernelGGL((median_hist_kernel<T>), dim3((unsigned)nch, (unsigned)rows), dim3(256), 0, s,
-                           static_cast<const T *>(x), red, chunk, d, st, ghist, gnan);
-        hipLaunchKernelGGL((median_pick_kernel<T>), dim3((unsigned)rows), dim3(64), 0, s, red, d, omitnan, st, ghist, gnan,
-                           static_cast<T *>(val));
+                           static_cast<const T *>(x), red, chunk, pass, st, ghist, gnan);
+        hipLaunchKernelGGL((median_pick_kernel<T>), dim3((unsigned)rows), dim3(64), 0, s, red, pass, omitnan, st, ghist,
+                           gnan, static_cast<T *>(val));
     }
     if (idx) {
         hipLaunchKernelGGL((median_index_kernel<T>), dim3((unsigned)nch, (unsigned)rows), dim3(256), 0, s,
@@ -453,7 +508,7 @@ extern "C" {
 size_t nfm_reduce_median_workspace_bytes(int64_t rows, int64_t red)
 {
     if (rows <= 0 || red <= med::kShortMax) return 0;
-    return (size_t)rows * (sizeof(med::RowState) + 256 * sizeof(unsigned) + sizeof(unsigned long long));
+    return (size_t)rows * (sizeof(med::RowState) + med::kLongBins * sizeof(unsigned) + sizeof(unsigned long long));
 }
 
 int nfm_reduce_median(int dtype, int omitnan, int64_t rows, int64_t red, const void *x, void *workspace,

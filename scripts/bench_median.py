@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""median (radix selection, nfm_reduce_median) against torch.median on the same device.
+usage: bench_median.py [--no-torch] > profiles/rNN/median_table.md"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nitorch_fastmath_amd as N  # noqa: E402
+
+dev = torch.device('cuda:0')
+with_torch = '--no-torch' not in sys.argv
+
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize(); best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize(); best = min(best, e0.elapsed_time(e1) * 1e-3)
+    return best
+
+
+print('# median: radix selection (nfm_reduce_median) vs torch.median on the same MI355X, contiguous (rows, red)\n')
+print('| dtype | shape (rows x red) | ours ms | GB/s of one pass | torch.median ms |')
+print('|---|---|---|---|---|')
+for dtype, shapes in ((torch.float32, ((1, 1 << 30), (64, 1 << 24), (1 << 14, 1 << 16), (1 << 20, 1024), (1 << 22, 256),
+                                       (1 << 24, 27), (1 << 25, 8))),
+                      (torch.float64, ((1, 1 << 29), (1 << 13, 1 << 16), (1 << 19, 1024)))):
+    for rows, red in shapes:
+        x = torch.randn(rows, red, device=dev, dtype=dtype)
+        t = timeit(lambda: N.reduce.median(x, dim=1))
+        tt = float('nan')
+        if with_torch:
+            try:
+                tt = timeit(lambda: torch.median(x, dim=1), reps=1)
+            except Exception:
+                pass
+        print(f'| {str(dtype)[6:]} | {rows} x {red} | {t * 1e3:.3f} | {rows * red * x.element_size() / t / 1e9:.0f} | {tt * 1e3:.3f} |')
+        del x
+print('\nGB/s = rows x red x element size / time: one pass over the data.  Rows longer than 1024 make one streaming pass '
+      'per 11-bit digit of the key (3 for float32, 6 for float64); rows up to 1024 are read once (keys stay in registers).  '
+      'torch.median sorts every row (and is serial within one 2^30-element row).')
