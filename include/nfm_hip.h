@@ -276,11 +276,14 @@ int nfm_qr_rq_hessenberg(int dtype, int N, int sym, int64_t n_outer, int64_t n_i
  * flags: NFM_EIG_VECTORS        also compute the eigenvectors (`compute_u`);
  *        NFM_EIG_REFERENCE_ORDER run the QR sweeps in the reference's operation order with IEEE
  *                                division / square root -- bit-identical to the CPU restatement
- *                                (same deflation order, same eigenvector signs) at about half the
- *                                throughput.  Without it the sweeps use v_rsq + Newton steps (one
- *                                for float32, two for float64) and fma contraction: as accurate
- *                                against the exact eigenvalues, but order and signs may differ
- *                                (both are unspecified by the reference: `qr.py:45-46`). */
+ *                                (same deflation order, same eigenvector signs) at a third to a
+ *                                quarter of the throughput.  Without it the sweeps use v_rsq +
+ *                                Newton steps (one for float32, two for float64) and fma
+ *                                contraction, the last 2x2 block is diagonalised by one Jacobi
+ *                                rotation, and `tol` is floored at the working precision of the
+ *                                dtype, max(tol, (eps/4)^2): as accurate against the exact
+ *                                eigenvalues, but order and signs may differ (both are
+ *                                unspecified by the reference: `qr.py:45-46`). */
 #define NFM_EIG_VECTORS 1
 #define NFM_EIG_REFERENCE_ORDER 2
 int nfm_qr_eig_sym(int dtype, int N, int upper, int flags, int max_iter, double tol,
