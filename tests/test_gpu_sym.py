@@ -185,6 +185,18 @@ def test_packed_records_at_any_batch_stride(dev, oracle, dn, M):
     S.sym_solve(z[..., 1], zv[..., 0].clone(), out=zv[..., 0])
     check(zv[..., 0], ref, dn, ex)
     assert bool((zv[..., 1] == 7).all())
+    # in place on strided views: every lane reads its record before it writes it
+    vb = torch.zeros(2 * n, M, dtype=md.dtype, device=dev)
+    vb[::2] = vd
+    r = S.sym_solve_(md, vb[::2])
+    assert r.data_ptr() == vb.data_ptr()
+    check(vb[::2], ref, dn, ex)
+    assert bool((vb[1::2] == 0).all())
+    mb = torch.zeros(n, 2 * K, dtype=md.dtype, device=dev)
+    mb[:, :K] = md
+    S.sym_invert_(mb[:, :K])
+    check(mb[:, :K], refinv, dn, ex)
+    assert bool((mb[:, K:] == 0).all())
     # cropped 2-D field: rows of contiguous records, outer stride larger than the row
     X, Y = 3, 257
     m2, v2 = md[:X * Y].reshape(X, Y, K), vd[:X * Y].reshape(X, Y, M)
