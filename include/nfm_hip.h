@@ -209,7 +209,8 @@ int nfm_reduce_stat(int dtype, int stat, int out_dtype, int64_t outer, int64_t r
 
 /* Median of every row of a contiguous (rows, red) array, `median` `reduce.py:384-428` (which
  * moves the reduced dims last and calls torch.median; the facade does the same move): the
- * LOWER median (rank (count - 1) / 2), by radix selection on order-preserving integer keys.
+ * LOWER median (rank (count - 1) / 2), on order-preserving integer keys: a register sorting network
+ * per row for rows of up to 128 elements (float64: 64), radix selection for longer ones.
  * omitnan = 0: a NaN in a row makes its median NaN (idx: the first NaN) -- what the reference
  * computes; omitnan = 1: the median of the non-NaN elements (all NaN: NaN, idx 0) -- what its
  * docstring promises (quirk Q14).  val: (rows) of `dtype`; idx: (rows) int64 or NULL = the first

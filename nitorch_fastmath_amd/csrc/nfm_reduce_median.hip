@@ -14,6 +14,8 @@
 // count the elements per digit value among those that match the digits chosen so far, keep the
 // digit whose cumulative count passes k.  No data movement.
 //
+//   red <= 128:  (float64: 64) one row per LANE, sorted in registers by a compile-time merge-exchange
+//                network; with fewer than 4096 rows, or beyond that length:
 //   red <= 32:   8 / 16 / 32 lanes per row, one element per lane, ranks counted directly;
 //   red <= 1024: one WAVEFRONT per row, the row in registers (<= 16 keys per lane), a 256-bin LDS
 //                histogram per wavefront, ds_add for the counts, a 64-lane scan to pick the digit;
@@ -23,45 +25,10 @@
 //                a trip over HBM, so the digits are 11 bits wide (2048 bins, 8 KiB of LDS): 3 passes
 //                for float32 (11 + 11 + 10 bits), 6 for float64 -- a full reduction of 2^33
 //                elements is 3 passes at the streaming rate.
-#include "nfm_reduce_common.hpp"
+#include "nfm_reduce_median.hpp"
 
 namespace nfm {
 namespace med {
-
-template <typename T>
-struct Key;
-template <>
-struct Key<float> {
-    using U = uint32_t;
-    static constexpr int digits = 4;
-    static __device__ __forceinline__ U of(float x)
-    {
-        const U u = (U)__float_as_int(x);
-        if (x != x) return ~U(0);
-        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    }
-    static __device__ __forceinline__ float back(U k)
-    {
-        const U u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-        return __int_as_float((int)u);
-    }
-};
-template <>
-struct Key<double> {
-    using U = uint64_t;
-    static constexpr int digits = 8;
-    static __device__ __forceinline__ U of(double x)
-    {
-        const U u = (U)__double_as_longlong(x);
-        if (x != x) return ~U(0);
-        return (u >> 63) ? ~u : (u | (U(1) << 63));
-    }
-    static __device__ __forceinline__ double back(U k)
-    {
-        const U u = (k >> 63) ? (k & ~(U(1) << 63)) : ~k;
-        return __longlong_as_double((long long)u);
-    }
-};
 
 __device__ __forceinline__ unsigned wave_excl_scan(unsigned v, unsigned &total)
 {
@@ -429,6 +396,7 @@ __global__ void median_store_index_kernel(int64_t rows, int64_t red, const RowSt
 }
 
 constexpr int kShortMax = 1024;
+constexpr int64_t kLaneMinRows = 4096; // below this the rows do not fill the lanes of the chip: the group kernel
 
 static int64_t chunk_of(int64_t rows, int64_t red)
 {
@@ -445,6 +413,20 @@ static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, 
                void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (red >= 2 && red <= LaneMax<T>::value && rows >= kLaneMinRows && reinterpret_cast<uintptr_t>(x) % sizeof(T) == 0) {
+        // one row per lane (nfm_reduce_median_lane.hip, one object per residue of the length mod 8)
+        const int dt = sizeof(T) == 4 ? NFM_F32 : NFM_F64;
+        switch ((int)red % kLaneParts) {
+        case 0: return lane_part0(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        case 1: return lane_part1(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        case 2: return lane_part2(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        case 3: return lane_part3(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        case 4: return lane_part4(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        case 5: return lane_part5(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        case 6: return lane_part6(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        default: return lane_part7(dt, (int)red, omitnan, rows, x, val, idx, stream);
+        }
+    }
     if (red <= 32) {
         const int G = red <= 8 ? 8 : (red <= 16 ? 16 : 32);
         const int64_t nblk = (rows + 4 * (64 / G) - 1) / (4 * (64 / G));

@@ -1,0 +1,60 @@
+// nfm_reduce_median.hpp -- pieces shared by nfm_reduce_median.hip (radix selection) and
+// nfm_reduce_median_lane.hip (one row per lane): the order-preserving integer keys.
+#pragma once
+#include "nfm_reduce_common.hpp"
+
+namespace nfm {
+namespace med {
+
+template <typename T>
+struct Key;
+template <>
+struct Key<float> {
+    using U = uint32_t;
+    static constexpr int digits = 4;
+    static __device__ __forceinline__ U of(float x)
+    {
+        const U u = (U)__float_as_int(x);
+        if (x != x) return ~U(0);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    static __device__ __forceinline__ float back(U k)
+    {
+        const U u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+        return __int_as_float((int)u);
+    }
+};
+template <>
+struct Key<double> {
+    using U = uint64_t;
+    static constexpr int digits = 8;
+    static __device__ __forceinline__ U of(double x)
+    {
+        const U u = (U)__double_as_longlong(x);
+        if (x != x) return ~U(0);
+        return (u >> 63) ? ~u : (u | (U(1) << 63));
+    }
+    static __device__ __forceinline__ double back(U k)
+    {
+        const U u = (k >> 63) ? (k & ~(U(1) << 63)) : ~k;
+        return __longlong_as_double((long long)u);
+    }
+};
+
+// longest row sorted by one lane (nfm_reduce_median_lane.hip): the keys live in registers (128 / 2 x 64
+// VGPRs) and the workgroup's LDS image stays at 32 KiB with 64-lane tiles
+template <typename T>
+struct LaneMax {
+    static constexpr int value = sizeof(T) == 4 ? 128 : 64;
+};
+constexpr int kLaneParts = 8; // the lane kernels are compiled in 8 objects: row lengths by their residue mod 8
+
+// part `p` serves the row lengths red with red % 8 == p; returns NFM_EINVAL for a length it does not hold
+#define NFM_MED_LANE_DECL(p) \
+    int lane_part##p(int dtype, int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, void *stream);
+NFM_MED_LANE_DECL(0) NFM_MED_LANE_DECL(1) NFM_MED_LANE_DECL(2) NFM_MED_LANE_DECL(3)
+NFM_MED_LANE_DECL(4) NFM_MED_LANE_DECL(5) NFM_MED_LANE_DECL(6) NFM_MED_LANE_DECL(7)
+#undef NFM_MED_LANE_DECL
+
+} // namespace med
+} // namespace nfm

@@ -23,8 +23,8 @@ print('# median: radix selection (nfm_reduce_median) vs torch.median on the same
 print('| dtype | shape (rows x red) | ours ms | GB/s of one pass | torch.median ms |')
 print('|---|---|---|---|---|')
 for dtype, shapes in ((torch.float32, ((1, 1 << 30), (64, 1 << 24), (1 << 14, 1 << 16), (1 << 20, 1024), (1 << 22, 256),
-                                       (1 << 24, 27), (1 << 25, 8))),
-                      (torch.float64, ((1, 1 << 29), (1 << 13, 1 << 16), (1 << 19, 1024)))):
+                                       (1 << 22, 129), (1 << 22, 128), (1 << 22, 125), (1 << 23, 81), (1 << 23, 64), (1 << 23, 49), (1 << 24, 27), (1 << 25, 8))),
+                      (torch.float64, ((1, 1 << 29), (1 << 13, 1 << 16), (1 << 19, 1024), (1 << 22, 65), (1 << 22, 64), (1 << 23, 27), (1 << 24, 8)))):
     for rows, red in shapes:
         x = torch.randn(rows, red, device=dev, dtype=dtype)
         t = timeit(lambda: N.reduce.median(x, dim=1))

@@ -468,6 +468,39 @@ def test_median_vs_oracle_and_torch(dev, oracle, dn, red):
     assert float(flat) == float(oracle.median(x.reshape(-1), None, omitnan=True)[0])
 
 
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_median_row_per_lane(dev, oracle, dn):
+    """rows of 2..128 (float64: 2..64) elements in batches of >= 4096 rows: one row per lane, sorted in registers by
+    the merge-exchange network (median_lane_kernel) -- every length, ragged last tile, NaNs (kept and
+    omitted), signed zeros, infinities, ties; values and first-position indices equal to the oracle's,
+    bit for bit, and to the few-rows kernel's on the same rows"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    for red in range(2, 130 if dn == 'f32' else 66):      # one past the limit: the wavefront-per-row kernel
+        rng = np.random.default_rng(1000 + red)
+        rows = 4096 + 3 * 256 + 41
+        x = rng.standard_normal((rows, red)).astype(dtype)
+        x[::7] = np.round(x[::7] * 2) / 2                                   # ties
+        x[rng.random((rows, red)) < 0.03] = np.nan
+        x[5] = np.nan                                                       # all NaN
+        x[6, 0], x[6, -1] = np.inf, -np.inf
+        x[8] = 0.0
+        x[8, ::2] = -0.0                                                    # signed zeros only
+        xd = t(x, dev)
+        for omit in (False, True):
+            v, i = R().median(xd, dim=1, omitnan=omit, return_indices=True)
+            v0 = R().median(xd, dim=1, omitnan=omit)
+            rv, ri = oracle.median(x, 1, omitnan=omit)
+            v, i, v0 = v.cpu().numpy(), i.cpu().numpy(), v0.cpu().numpy()
+            assert np.array_equal(v.view(np.uint8), v0.view(np.uint8))      # with and without the index output
+            nn = ~np.isnan(rv)
+            assert np.array_equal(np.isnan(v), np.isnan(rv)), (red, omit)
+            assert np.array_equal(v[nn].view(np.uint8), rv[nn].view(np.uint8)), (red, omit)
+            assert np.array_equal(i, ri), (red, omit)
+            few = R().median(xd[:100], dim=1, omitnan=omit, return_indices=True)     # < 4096 rows: the group kernel
+            assert np.array_equal(few[0].cpu().numpy().view(np.uint8), v[:100].view(np.uint8))
+            assert np.array_equal(few[1].cpu().numpy(), i[:100])
+
+
 def test_median_large(dev):
     """2^27 elements in one row (the dim=None form of a volume): 4 streaming passes; against a full
     device sort (torch.nanmedian on the device returned another element for this input), plus a 3-D
