@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NFM_VERSION 2 /* 2: nfm_qr_eig_sym takes flags (NFM_EIG_*); nfm_reduce_median added */
+#define NFM_VERSION 3 /* 2: nfm_qr_eig_sym takes flags (NFM_EIG_*); nfm_reduce_median added; 3: nfm_reduce_median_mid */
 #define NFM_MAX_DIM 16 /* largest matrix order handled (3x3 .. 16x16 and below) */
 
 /* dtype codes */
@@ -219,6 +219,15 @@ int nfm_reduce_stat(int dtype, int stat, int out_dtype, int64_t outer, int64_t r
 size_t nfm_reduce_median_workspace_bytes(int64_t rows, int64_t red);
 int nfm_reduce_median(int dtype, int omitnan, int64_t rows, int64_t red, const void *x, void *workspace,
                       size_t workspace_bytes, void *val, void *idx, void *stream);
+
+/* The same median over the MIDDLE dim of a contiguous (outer, red, inner) array -- the channel dim of a
+ * channel-first field -- without the transposing copy that moving the reduced dim last would cost (the
+ * reference makes that copy: `reduce.py:112-113`).  One row per lane, so only for
+ * 2 <= red <= nfm_reduce_median_lane_max(dtype) (128 for float32, 64 for float64; NFM_ESIZE beyond).
+ * val / idx: (outer, inner), idx = position along the reduced dim. */
+int nfm_reduce_median_lane_max(int dtype);
+int nfm_reduce_median_mid(int dtype, int omitnan, int64_t outer, int64_t red, int64_t inner, const void *x, void *val,
+                          void *idx, void *stream);
 
 /* ------------------------------------------------------------------- qr ---- */
 /* Real dtypes.  Multi-output routines write ONE packed, contiguous output record per

@@ -52,6 +52,8 @@ SIGNATURES = {
     'nfm_reduce_stat': [_i, _i, _i, _i64, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp],
     'nfm_reduce_median_workspace_bytes': [_i64, _i64],
     'nfm_reduce_median': [_i, _i, _i64, _i64, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp],
+    'nfm_reduce_median_lane_max': [_i],
+    'nfm_reduce_median_mid': [_i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     'nfm_qr_givens': [_i, _i64, _i64, _op, _op, _vp, _vp],
     'nfm_qr_givens_apply': [_i, _i, _i, _i, _i, _i64, _i64, _op, _op, _op, _vp],
     'nfm_qr_householder': [_i, _i, _i, _i64, _i64, _op, _vp, _vp],

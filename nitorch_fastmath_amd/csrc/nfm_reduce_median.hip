@@ -408,25 +408,29 @@ static int64_t chunk_of(int64_t rows, int64_t red)
     return ((chunk + 1023) / 1024) * 1024;
 }
 
+// one row per lane (nfm_reduce_median_lane.hip, one object per residue of the length mod 8)
+static int lane_any(int dt, int red, int omitnan, int64_t rows, int64_t inner, const void *x, void *val, void *idx,
+                    void *stream)
+{
+    switch (red % kLaneParts) {
+    case 0: return lane_part0(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    case 1: return lane_part1(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    case 2: return lane_part2(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    case 3: return lane_part3(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    case 4: return lane_part4(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    case 5: return lane_part5(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    case 6: return lane_part6(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    default: return lane_part7(dt, red, omitnan, rows, inner, x, val, idx, stream);
+    }
+}
+
 template <typename T>
 static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, size_t ws_bytes, void *val, void *idx,
                void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (red >= 2 && red <= LaneMax<T>::value && rows >= kLaneMinRows && reinterpret_cast<uintptr_t>(x) % sizeof(T) == 0) {
-        // one row per lane (nfm_reduce_median_lane.hip, one object per residue of the length mod 8)
-        const int dt = sizeof(T) == 4 ? NFM_F32 : NFM_F64;
-        switch ((int)red % kLaneParts) {
-        case 0: return lane_part0(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        case 1: return lane_part1(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        case 2: return lane_part2(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        case 3: return lane_part3(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        case 4: return lane_part4(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        case 5: return lane_part5(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        case 6: return lane_part6(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        default: return lane_part7(dt, (int)red, omitnan, rows, x, val, idx, stream);
-        }
-    }
+    if (red >= 2 && red <= LaneMax<T>::value && rows >= kLaneMinRows && reinterpret_cast<uintptr_t>(x) % sizeof(T) == 0)
+        return lane_any(sizeof(T) == 4 ? NFM_F32 : NFM_F64, (int)red, omitnan, rows, 1, x, val, idx, stream);
     if (red <= 32) {
         const int G = red <= 8 ? 8 : (red <= 16 ? 16 : 32);
         const int64_t nblk = (rows + 4 * (64 / G) - 1) / (4 * (64 / G));
@@ -491,6 +495,23 @@ size_t nfm_reduce_median_workspace_bytes(int64_t rows, int64_t red)
 {
     if (rows <= 0 || red <= med::kShortMax) return 0;
     return (size_t)rows * (sizeof(med::RowState) + med::kLongBins * sizeof(unsigned) + sizeof(unsigned long long));
+}
+
+int nfm_reduce_median_lane_max(int dtype)
+{
+    return dtype == NFM_F32 ? med::LaneMax<float>::value : (dtype == NFM_F64 ? med::LaneMax<double>::value : 0);
+}
+
+int nfm_reduce_median_mid(int dtype, int omitnan, int64_t outer, int64_t red, int64_t inner, const void *x, void *val,
+                          void *idx, void *stream)
+{
+    if (dtype != NFM_F32 && dtype != NFM_F64) return NFM_EDTYPE;
+    if (outer < 0 || red < 0 || inner < 0) return NFM_EINVAL;
+    if (outer == 0 || inner == 0) return NFM_OK;
+    if (red < 2 || red > nfm_reduce_median_lane_max(dtype)) return NFM_ESIZE;
+    if (x == nullptr || val == nullptr) return NFM_EINVAL;
+    if (reinterpret_cast<uintptr_t>(x) % (dtype == NFM_F32 ? 4 : 8) != 0) return NFM_EALIGN;
+    return med::lane_any(dtype, (int)red, omitnan ? 1 : 0, outer * inner, inner, x, val, idx, stream);
 }
 
 int nfm_reduce_median(int dtype, int omitnan, int64_t rows, int64_t red, const void *x, void *workspace,

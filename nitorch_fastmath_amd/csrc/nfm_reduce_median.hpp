@@ -49,9 +49,11 @@ struct LaneMax {
 };
 constexpr int kLaneParts = 8; // the lane kernels are compiled in 8 objects: row lengths by their residue mod 8
 
-// part `p` serves the row lengths red with red % 8 == p; returns NFM_EINVAL for a length it does not hold
+// part `p` serves the row lengths red with red % 8 == p; returns NFM_EINVAL for a length it does not hold.
+// rows = number of rows; inner = 1 for contiguous rows, else the (outer, red, inner) layout (rows = outer * inner)
 #define NFM_MED_LANE_DECL(p) \
-    int lane_part##p(int dtype, int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, void *stream);
+    int lane_part##p(int dtype, int red, int omitnan, int64_t rows, int64_t inner, const void *x, void *val, void *idx, \
+                     void *stream);
 NFM_MED_LANE_DECL(0) NFM_MED_LANE_DECL(1) NFM_MED_LANE_DECL(2) NFM_MED_LANE_DECL(3)
 NFM_MED_LANE_DECL(4) NFM_MED_LANE_DECL(5) NFM_MED_LANE_DECL(6) NFM_MED_LANE_DECL(7)
 #undef NFM_MED_LANE_DECL

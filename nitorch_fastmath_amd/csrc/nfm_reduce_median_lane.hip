@@ -96,14 +96,21 @@ __device__ __forceinline__ void sort_network(Keys<U, RED> &s)
     apply_network<U, RED>(s, std::make_index_sequence<(size_t)MergeExchange<RED>::count()>{});
 }
 
+constexpr int64_t kMidGrid2D = 2048; // middle-dim layout: planes at least this wide take the 2-D grid
+
 template <int RED, typename T>
 struct LaneTile {
     static constexpr int value = RED * (int)sizeof(T) * 256 <= 36 * 1024 ? 256 : (RED * (int)sizeof(T) * 128 <= 36 * 1024 ? 128 : 64);
 };
 
+// `inner` = 1: the rows are contiguous, (rows, RED).  `inner` > 1: the array is (outer, RED, inner) and the
+// MIDDLE dim is reduced (a channel dim of a channel-first field): row (o, i) has its elements `inner` apart,
+// consecutive lanes hold consecutive i -- every load is already coalesced, no LDS transpose, and the facade
+// does not have to move the reduced dim last (a transposing copy of the whole tensor) first.
 template <typename T, int RED>
 __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(const T *__restrict__ x, int64_t rows,
-                                                                                int omitnan, T *__restrict__ val,
+                                                                                int64_t inner, int omitnan,
+                                                                                T *__restrict__ val,
                                                                                 int64_t *__restrict__ idx)
 {
     using K = Key<T>;
@@ -111,23 +118,57 @@ __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(
     constexpr int TILE = LaneTile<RED, T>::value;
     using IO = TileIO<T, RED, TILE>;
     __shared__ __align__(16) unsigned char smem[IO::kLdsBytes];
+    const bool mid = inner != 1; // uniform
+    // row of this lane, and for the middle-dim layout its (o, i).  No 64-bit division (a 64-iteration
+    // software loop per lane: it cost 3x the rest of the kernel): wide planes take a 2-D grid, blockIdx.y
+    // + 65535 blockIdx.z = o; narrow ones (inner < kMidGrid2D) a 32-bit division (rows < 2^31 there).
+    const bool grid2d = mid && gridDim.y * gridDim.z > 1;
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    const int64_t row = tile0 + threadIdx.x;
-    typename IO::Stage st;
-    IO::issue(x + tile0 * RED, (rows - tile0) * RED, st);
-    IO::commit(smem, st);
-    __syncthreads();
-    // this lane's row in the LDS image (read element by element: no second register array)
-    const T *own = reinterpret_cast<const T *>(smem + threadIdx.x * IO::kRowStride);
+    int64_t row = tile0 + threadIdx.x, mo = 0, mi = 0;
+    bool live = row < rows;
+    if (mid) {
+        if (grid2d) {
+            mo = (int64_t)blockIdx.y + 65535LL * blockIdx.z;
+            mi = tile0 + threadIdx.x;
+            live = mi < inner && mo * inner + mi < rows;
+            row = mo * inner + (mi < inner ? mi : inner - 1);
+        } else {
+            const unsigned rr = (unsigned)(live ? row : rows - 1);
+            const unsigned q = rr / (unsigned)inner;
+            mo = q;
+            mi = rr - q * (unsigned)inner;
+        }
+    }
     Keys<U, RED> s;
     unsigned nan = 0;
+    // this lane's row: in the LDS image, or in global memory with its elements `inner` apart (two
+    // pointers, so that neither becomes a flat pointer)
+    const T *lown = reinterpret_cast<const T *>(smem + threadIdx.x * IO::kRowStride);
+    const T *gown = x;
+    if (!mid) {
+        typename IO::Stage st;
+        IO::issue(x + tile0 * RED, (rows - tile0) * RED, st);
+        IO::commit(smem, st);
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RED; ++i) {
-        const T v = own[i];
-        s.at(i) = K::of(v);
-        nan += (v != v) ? 1u : 0u;
-        // keep the scheduler from hoisting all RED reads above the conversions (2 x RED live registers)
-        if (i % 32 == 31) __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < RED; ++i) {
+            const T v = lown[i];
+            s.at(i) = K::of(v);
+            nan += (v != v) ? 1u : 0u;
+            // keep the scheduler from hoisting all RED reads above the conversions (2 x RED live registers)
+            if (i % 32 == 31) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // (lanes past the end redo a valid row and store nothing)
+        if (grid2d && mo * inner >= rows) mo = 0;
+        gown = x + (mo * RED) * inner + (mi < inner ? mi : inner - 1);
+#pragma unroll
+        for (int i = 0; i < RED; ++i) {
+            const T v = NFM_LDG(gown + i * inner);
+            s.at(i) = K::of(v);
+            nan += (v != v) ? 1u : 0u;
+            if (i % 32 == 31) __builtin_amdgcn_sched_barrier(0);
+        }
     }
     sort_network<U, RED>(s);
     const unsigned count = omitnan ? (unsigned)RED - nan : (unsigned)RED;
@@ -139,16 +180,24 @@ __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(
         for (int i = 0; i < RED; ++i) chosen = (k == (unsigned)i) ? s.at(i) : chosen;
     }
     if (want_nan) chosen = ~U(0);
-    if (row < rows) {
+    if (live) {
         val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
         if (idx != nullptr) { // uniform
-            // first position holding the chosen key (a NaN result: the first NaN): the row is still in
-            // the LDS image, so the unsorted keys need not stay in registers during the sort
+            // first position holding the chosen key (a NaN result: the first NaN): the row is read again
+            // (LDS image / global memory), so the unsorted keys need not stay in registers during the sort
             int first = 0;
+            if (!mid) {
 #pragma unroll
-            for (int i = RED - 1; i >= 0; --i) {
-                first = (K::of(own[i]) == chosen) ? i : first;
-                if (i % 32 == 0) __builtin_amdgcn_sched_barrier(0);
+                for (int i = RED - 1; i >= 0; --i) {
+                    first = (K::of(lown[i]) == chosen) ? i : first;
+                    if (i % 32 == 0) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int i = RED - 1; i >= 0; --i) {
+                    first = (K::of(gown[i * inner]) == chosen) ? i : first;
+                    if (i % 32 == 0) __builtin_amdgcn_sched_barrier(0);
+                }
             }
             idx[row] = first;
         }
@@ -156,37 +205,47 @@ __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(
 }
 
 template <typename T, int RED>
-static int run_lane(int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
+static int run_lane(int omitnan, int64_t rows, int64_t inner, const void *x, void *val, void *idx, hipStream_t s)
 {
     constexpr int TILE = LaneTile<RED, T>::value;
-    const int64_t nblk = (rows + TILE - 1) / TILE;
-    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
-    hipLaunchKernelGGL((median_lane_kernel<T, RED>), dim3((unsigned)nblk), dim3(TILE), 0, s, static_cast<const T *>(x),
-                       rows, omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx));
+    dim3 grid;
+    if (inner >= kMidGrid2D) { // one grid row per outer index: no division in the kernel
+        const int64_t outer = rows / inner, nbx = (inner + TILE - 1) / TILE;
+        const int64_t gy = outer < 65535 ? outer : 65535, gz = (outer + 65534) / 65535;
+        if (nbx > 0x7fffffffLL || gz > 65535) return NFM_ESIZE;
+        grid = dim3((unsigned)nbx, (unsigned)gy, (unsigned)gz);
+    } else {
+        const int64_t nblk = (rows + TILE - 1) / TILE;
+        if (nblk > 0x7fffffffLL || (inner != 1 && rows > 0x7fffffffLL)) return NFM_ESIZE;
+        grid = dim3((unsigned)nblk, 1, 1);
+    }
+    hipLaunchKernelGGL((median_lane_kernel<T, RED>), grid, dim3(TILE), 0, s, static_cast<const T *>(x), rows, inner,
+                       omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx));
     return launch_status();
 }
 
 // the lengths of this part, RED = first, first + 8, ... <= LaneMax
 template <typename T, int RED>
-static int lane_chain(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
+static int lane_chain(int red, int omitnan, int64_t rows, int64_t inner, const void *x, void *val, void *idx,
+                      hipStream_t s)
 {
     if constexpr (RED > LaneMax<T>::value) {
         return NFM_EINVAL;
     } else {
-        if (red == RED) return run_lane<T, RED>(omitnan, rows, x, val, idx, s);
-        return lane_chain<T, RED + kLaneParts>(red, omitnan, rows, x, val, idx, s);
+        if (red == RED) return run_lane<T, RED>(omitnan, rows, inner, x, val, idx, s);
+        return lane_chain<T, RED + kLaneParts>(red, omitnan, rows, inner, x, val, idx, s);
     }
 }
 
 #define NFM_MED_CAT2(a, b) a##b
 #define NFM_MED_CAT(a, b) NFM_MED_CAT2(a, b)
-int NFM_MED_CAT(lane_part, NFM_MED_LANE_PART)(int dtype, int red, int omitnan, int64_t rows, const void *x, void *val,
-                                              void *idx, void *stream)
+int NFM_MED_CAT(lane_part, NFM_MED_LANE_PART)(int dtype, int red, int omitnan, int64_t rows, int64_t inner,
+                                              const void *x, void *val, void *idx, void *stream)
 {
     constexpr int first = NFM_MED_LANE_PART >= 2 ? NFM_MED_LANE_PART : NFM_MED_LANE_PART + kLaneParts; // lengths start at 2
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dtype == NFM_F32 ? lane_chain<float, first>(red, omitnan, rows, x, val, idx, s)
-                            : lane_chain<double, first>(red, omitnan, rows, x, val, idx, s);
+    return dtype == NFM_F32 ? lane_chain<float, first>(red, omitnan, rows, inner, x, val, idx, s)
+                            : lane_chain<double, first>(red, omitnan, rows, inner, x, val, idx, s);
 }
 
 } // namespace med

@@ -286,8 +286,10 @@ def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_
     never does (SURVEY quirk Q14; pinned by tests/test_gpu_reduce.py::test_median_semantics).
     `omitnan=True` is the documented intent: the median of the non-NaN values (all-NaN -> NaN).
 
-    One radix-selection kernel (`nfm_reduce_median`): no sort, no copy of the data beyond the move
-    of the reduced dims to the end that the reference does too (`reduce.py:112-113`).
+    One kernel (`nfm_reduce_median`: a register sorting network per row for short rows, radix
+    selection for long ones), no copy of the data beyond the move of the reduced dims to the end that
+    the reference does too (`reduce.py:112-113`) -- and not even that one for short rows reduced in
+    the middle of a contiguous tensor (`nfm_reduce_median_mid`).
     """
     input = torch.as_tensor(input)
     dev = require_gpu(input)
@@ -306,16 +308,33 @@ def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_
     red, rows = _prod(redshape), _prod(subshape)
     if red == 0:
         raise IndexError('cannot take the median over an empty dimension')
-    xg = input.permute(kept + dims).reshape(rows, red)       # differentiable view / copy of the rows
-    x = xg.detach()
-    if not x.is_contiguous():
-        x = x.contiguous()
     val = torch.empty(rows, dtype=input.dtype, device=dev)
     want_idx = return_indices and dim is not None
     idx = torch.empty(rows, dtype=torch.long, device=dev) if (want_idx or grad) else None
     L = _lib.lib()
+    # A block of adjacent dims reduced in the MIDDLE of a contiguous tensor (the channel dim of a
+    # channel-first field): short rows are sorted one per lane straight from the (outer, red, inner)
+    # layout -- no transposing copy of the whole tensor first (upstream makes one, `reduce.py:112-113`).
+    d0 = builtins.min(dims)
+    inner = _prod(input.shape[d0 + len(dims):])
+    if (dims == list(range(d0, d0 + len(dims))) and inner > 1 and input.is_contiguous() and rows >= 4096
+            and 2 <= red <= L.nfm_reduce_median_lane_max(code)):
+        with on_device(dev):
+            _lib.check(L.nfm_reduce_median_mid(code, int(bool(omitnan)), rows // inner, red, inner,
+                                               input.detach().data_ptr(), val.data_ptr(),
+                                               idx.data_ptr() if idx is not None else None, stream_ptr(dev)))
+        rows_done = True
+    else:
+        rows_done = False
+    x = None
+    if grad or not rows_done:
+        xg = input.permute(kept + dims).reshape(rows, red)   # differentiable view / copy of the rows
+    if not rows_done:
+        x = xg.detach()
+        if not x.is_contiguous():
+            x = x.contiguous()
     step = rows if red <= 1024 else 65535          # long rows: grid.y bound of the histogram passes
-    for lo in range(0, rows, builtins.max(step, 1)):
+    for lo in ([] if rows_done else range(0, rows, builtins.max(step, 1))):
         hi = builtins.min(rows, lo + step)
         ws, wsn = _workspace(dev, L.nfm_reduce_median_workspace_bytes(hi - lo, red))
         with on_device(dev):

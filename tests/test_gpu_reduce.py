@@ -501,6 +501,41 @@ def test_median_row_per_lane(dev, oracle, dn):
             assert np.array_equal(few[1].cpu().numpy(), i[:100])
 
 
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_median_middle_dim_without_transpose(dev, oracle, dn):
+    """the channel dim (or a block of adjacent dims) of a contiguous channel-first field: one row per
+    lane straight from the (outer, red, inner) layout (nfm_reduce_median_mid) -- same values and indices
+    as moving the dims last first, which is what the other path (and upstream) does"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(77)
+    for shape, dim in (((3, 27, 40, 41), 1), ((2, 5, 5, 61, 37), (1, 2)), ((70, 9, 67), 1), ((4100, 2, 3), 1),
+                       ((2, 64 if dn == 'f64' else 128, 4099), 1), ((5, 3, 4, 1000), (1, 2))):
+        x = rng.standard_normal(shape).astype(dtype)
+        x[rng.random(shape) < 0.02] = np.nan
+        xd = t(x, dev)
+        dims = (dim,) if isinstance(dim, int) else dim
+        last = np.moveaxis(x, dims, tuple(range(-len(dims), 0)))
+        flat = np.ascontiguousarray(last).reshape(-1, int(np.prod([shape[d] for d in dims])))
+        for omit in (False, True):
+            v, i = R().median(xd, dim=dim, omitnan=omit, return_indices=True)
+            rv, ri = oracle.median(flat, 1, omitnan=omit)
+            v, i = v.cpu().numpy(), i.cpu().numpy()
+            rv = rv.reshape(v.shape)
+            nn = ~np.isnan(rv)
+            assert np.array_equal(np.isnan(v), np.isnan(rv)), (shape, omit)
+            assert np.array_equal(v[nn].view(np.uint8), rv[nn].view(np.uint8)), (shape, omit)
+            sub = np.stack(np.unravel_index(ri, [shape[d] for d in dims]), -1).reshape(v.shape + (len(dims),))
+            assert np.array_equal(i.reshape(sub.shape if len(dims) > 1 else v.shape),
+                                  sub if len(dims) > 1 else sub[..., 0]), (shape, omit)
+            # the same call on a transposed copy takes the rows path: identical
+            v2 = R().median(t(np.ascontiguousarray(last), dev), dim=tuple(range(-len(dims), 0)), omitnan=omit)
+            assert np.array_equal(v2.cpu().numpy().view(np.uint8), v.view(np.uint8))
+    # backward: the gradient goes to the selected element
+    xg = t(rng.standard_normal((2, 9, 5000)).astype(dtype), dev).requires_grad_(True)
+    R().median(xg, dim=1).sum().backward()
+    assert float(xg.grad.sum()) == 2 * 5000 and int((xg.grad != 0).sum()) == 2 * 5000
+
+
 def test_median_large(dev):
     """2^27 elements in one row (the dim=None form of a volume): 4 streaming passes; against a full
     device sort (torch.nanmedian on the device returned another element for this input), plus a 3-D
