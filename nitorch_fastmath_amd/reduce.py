@@ -298,6 +298,16 @@ def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_
         raise RuntimeError('out= is not supported for tensors that require grad')
     code = dtype_code(input.dtype)
     nd = input.dim()
+    if not grad and out is None and isinstance(dim, int) and not input.is_contiguous():
+        # a dim permutation of a contiguous tensor (the channel-last VIEW of a channel-first field):
+        # reduce the corresponding dim of the contiguous tensor in place instead of copying the view
+        canon = _canon(input, dim)
+        if canon is not None:
+            xp, mapped, inv, odims = canon
+            r = median(xp, mapped, True, omitnan, False, return_indices)
+            if return_indices:
+                return _uncanon(r[0], inv, odims, keepdim), _uncanon(r[1], inv, odims, keepdim)
+            return _uncanon(r, inv, odims, keepdim)
     scalar_dim = dim is not None and not isinstance(dim, (list, tuple, range))
     dims = list(range(nd)) if dim is None else [d if d >= 0 else nd + d for d in ensure_list(dim)]
     if len(set(dims)) != len(dims) or any(d < 0 or d >= nd for d in dims):

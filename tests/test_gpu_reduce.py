@@ -530,6 +530,16 @@ def test_median_middle_dim_without_transpose(dev, oracle, dn):
             # the same call on a transposed copy takes the rows path: identical
             v2 = R().median(t(np.ascontiguousarray(last), dev), dim=tuple(range(-len(dims), 0)), omitnan=omit)
             assert np.array_equal(v2.cpu().numpy().view(np.uint8), v.view(np.uint8))
+    # the channel-last VIEW of a channel-first field: reduced in place through the contiguous tensor
+    x = rng.standard_normal((2, 9, 70, 71)).astype(dtype)
+    xd = t(x, dev)
+    view = xd.movedim(1, -1)
+    assert not view.is_contiguous()
+    for keep in (False, True):
+        v, i = R().median(view, dim=-1, keepdim=keep, return_indices=True)
+        rv, ri = R().median(view.contiguous(), dim=-1, keepdim=keep, return_indices=True)
+        assert v.shape == rv.shape and torch.equal(v, rv) and torch.equal(i, ri)
+    assert torch.equal(R().median(view, dim=0), R().median(view.contiguous(), dim=0))
     # backward: the gradient goes to the selected element
     xg = t(rng.standard_normal((2, 9, 5000)).astype(dtype), dev).requires_grad_(True)
     R().median(xg, dim=1).sum().backward()
