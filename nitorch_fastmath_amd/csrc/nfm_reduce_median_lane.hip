@@ -13,8 +13,8 @@ namespace nfm {
 namespace med {
 
 // ---------------------------------------------------------------------------------------------
-// rows of 2..128 elements (float64: 2..64), ONE ROW PER LANE: the rows of a contiguous (rows, RED) array are records
-// like the small matrices of the other kernels -- the workgroup streams its TILE * RED elements with
+// rows of 2..128 elements (float64: 2..64), ONE ROW PER LANE: the rows of a contiguous (rows, RED) array are
+// records like the small matrices of the other kernels -- the workgroup streams its TILE * RED elements with
 // 16-byte loads through the LDS transpose (TileIO), every lane picks up its row, sorts the RED keys
 // in registers with Batcher's odd-even merge network (compile-time indices: v_min_u32 / v_max_u32 per
 // comparator, no cross-lane traffic, ~160 comparators for 27 keys) and reads the key of rank k off
@@ -27,9 +27,8 @@ __device__ __forceinline__ void cmpxchg(U &a, U &b)
     b = hi;
 }
 
-// The RED keys of a lane, held as two register arrays: the compiler keeps a private array in VGPRs only
-// up to a size limit (an array of more than ~100 dwords went to scratch memory, 50x slower), and every
-// index below is a compile-time constant after unrolling, so the split costs nothing.
+// The RED keys of a lane, held as two register arrays (the promotion of ONE large private array to VGPRs is
+// subject to a size limit of the compiler; every index used below is a literal, so the split is free).
 template <typename U, int RED>
 struct Keys {
     static constexpr int H = RED > 64 ? (RED + 1) / 2 : RED;
