@@ -29,7 +29,7 @@ namespace nfm {
         return NFM_ESIZE;                \
     }
 
-// One matrix (per outer slab) solved against many vectors, closed forms (M <= 4): the cofactors and
+// One matrix (per outer slab) solved against many vectors (M <= 8).  Closed forms (M <= 4): the cofactors and
 // the determinant are derived once per lane and applied to V right-hand sides -- the same operations
 // in the same order as SolveOp (sym_solve_prepare / sym_solve_apply are the two halves of
 // sym_solve_closed), so the results are bit for bit the per-record kernel's, at 16 multiply-adds and
@@ -49,17 +49,36 @@ __global__ __launch_bounds__(256) void sym_solve_bcast_kernel(Opnd mat, Opnd vec
 #pragma unroll
         for (int i = 0; i < M; ++i) a[i] += (T)p.eps[i];
     }
-    T co[SymCofLen<M>::value], det;
-    sym_solve_prepare<T, M>(a, co, det);
     const int64_t base = (int64_t)blockIdx.x * (256 * V) + threadIdx.x;
     T v[V][M];
 #pragma unroll
     for (int q = 0; q < V; ++q) rec_direct_load<T, RV>(vec, vec.tiled, o, base + q * 256, base + q * 256 < n_inner, v[q]);
+    if constexpr (M <= 4) {
+        T co[SymCofLen<M>::value], det;
+        sym_solve_prepare<T, M>(a, co, det);
 #pragma unroll
-    for (int q = 0; q < V; ++q) {
-        T r[M];
-        sym_solve_apply<T, M>(co, det, v[q], r);
-        rec_direct_store<T, RV>(out, out.tiled, o, base + q * 256, base + q * 256 < n_inner, r);
+        for (int q = 0; q < V; ++q) {
+            T r[M];
+            sym_solve_apply<T, M>(co, det, v[q], r);
+            rec_direct_store<T, RV>(out, out.tiled, o, base + q * 256, base + q * 256 < n_inner, r);
+        }
+    } else {
+        // orders 5..8: the elimination with partial pivoting of SolveOp, once, with the V vectors as the columns
+        // of one right-hand side (ge_solve treats every column independently: the same bits per system)
+        T f[M][M], b[M][V];
+        sym_expand<T, M>(a, f);
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int q = 0; q < V; ++q) b[i][q] = v[q][i];
+        ge_solve<T, M, V>(f, b);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            T r[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) r[i] = b[i][q];
+            rec_direct_store<T, RV>(out, out.tiled, o, base + q * 256, base + q * 256 < n_inner, r);
+        }
     }
 }
 
@@ -84,11 +103,15 @@ static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operan
                        const nfm_operand *out, const SolveParams &p, void *stream)
 {
     // a matrix that is the same along the inner batch level (stride 0: one Hessian, many gradients)
-    if (kind == NFM_MAT_SYM && M >= 2 && M <= 4 && mat->stride_inner == 0 && ni >= 1024) {
+    if (kind == NFM_MAT_SYM && M >= 2 && M <= 8 && mat->stride_inner == 0 && ni >= 1024) {
         switch (M) {
         case 2: return sym_solve_bcast<T, 2>(no, ni, mat, vec, out, p, stream);
         case 3: return sym_solve_bcast<T, 3>(no, ni, mat, vec, out, p, stream);
-        default: return sym_solve_bcast<T, 4>(no, ni, mat, vec, out, p, stream);
+        case 4: return sym_solve_bcast<T, 4>(no, ni, mat, vec, out, p, stream);
+        case 5: return sym_solve_bcast<T, 5>(no, ni, mat, vec, out, p, stream);
+        case 6: return sym_solve_bcast<T, 6>(no, ni, mat, vec, out, p, stream);
+        case 7: return sym_solve_bcast<T, 7>(no, ni, mat, vec, out, p, stream);
+        default: return sym_solve_bcast<T, 8>(no, ni, mat, vec, out, p, stream);
         }
     }
     if (M > 8) {
