@@ -359,9 +359,12 @@ def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_
     val = _deliver(val, out_val)
     if not want_idx:
         return val
-    sub = torch.movedim(ind2sub(idx.reshape(shape), redshape), 0, -1)
-    if scalar_dim:
-        sub = sub[..., 0]
+    if len(redshape) == 1:                # one reduced dim: the position along it IS the sub-index
+        sub = idx.reshape(shape) if scalar_dim else idx.reshape(shape).unsqueeze(-1)
+    else:
+        sub = torch.movedim(ind2sub(idx.reshape(shape), redshape), 0, -1)
+        if scalar_dim:
+            sub = sub[..., 0]
     return val, _deliver(sub, out_ind)
 
 
