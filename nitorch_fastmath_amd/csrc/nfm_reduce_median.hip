@@ -17,8 +17,9 @@
 //   red <= 128:  (float64: 64) one row per LANE, sorted in registers by a compile-time merge-exchange
 //                network; with fewer than 4096 rows, or beyond that length:
 //   red <= 32:   8 / 16 / 32 lanes per row, one element per lane, ranks counted directly;
-//   red <= 1024: one WAVEFRONT per row, the row in registers (<= 16 keys per lane), a 256-bin LDS
-//                histogram per wavefront, ds_add for the counts, a 64-lane scan to pick the digit;
+//   red <= 1024: 16 / 32 / 64 lanes per row (4 / 2 / 1 rows per WAVEFRONT), the row in registers (<= 16 keys
+//                per lane), a 256-bin LDS histogram per row, ds_add for the counts, a scan inside the
+//                group to pick the digit;
 //   longer rows: every pass streams the row once with 16-byte loads -- a grid of (chunks, rows)
 //                workgroups histograms into LDS and adds its counts to the row's global histogram;
 //                a one-wavefront kernel per row picks the digit between passes.  Here a pass costs
@@ -75,7 +76,7 @@ __device__ __forceinline__ unsigned pick_digit(const unsigned (&cnt)[4], unsigne
 }
 
 // ---------------------------------------------------------------------------------------------
-// short rows: one wavefront per row
+// short rows: one wavefront per 1 / 2 / 4 rows
 // the part of a key above digit d (0 for the top digit: nothing chosen yet)
 template <typename U>
 __device__ __forceinline__ U above(U key, int d, int digits)
@@ -83,78 +84,108 @@ __device__ __forceinline__ U above(U key, int d, int digits)
     return d + 1 < digits ? (U)(key >> (8 * (d + 1))) : U(0);
 }
 
-// E = keys per lane: rows of up to 64 * E elements
-template <typename T, int E>
+// G lanes per row (16 / 32 / 64: 4 / 2 / 1 rows per wavefront), E keys per lane: rows of up to G * E
+// elements.  The per-pass frame (clear the histogram, scan it, pick the digit) is the same instruction
+// stream whatever the row length, so short rows share a wavefront: 4 rows of <= 256 elements cost what
+// one did.  Every row has its own 256-bin histogram; the scan and the broadcasts run inside the group.
+template <typename T, int E, int G>
 __global__ __launch_bounds__(256) void median_rows_kernel(const T *__restrict__ x, int64_t rows, int red, int omitnan,
                                                           T *__restrict__ val, int64_t *__restrict__ idx)
 {
     using K = Key<T>;
     using U = typename K::U;
-    __shared__ unsigned hist_all[4][256];
+    constexpr int RPW = 64 / G;  // rows per wavefront
+    constexpr int NB = 256 / G;  // histogram bins owned by a lane
+    __shared__ unsigned hist_all[4][RPW][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned *hist = hist_all[w];
-    const int64_t row = (int64_t)blockIdx.x * 4 + w;
-    if (row >= rows) return; // whole wavefronts leave: no barrier below is workgroup-wide
-    const T *p = x + row * red;
+    const int g = lane / G, j = lane % G;
+    unsigned *hist = hist_all[w][g];
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * RPW;
+    if (row0 >= rows) return; // whole wavefronts leave: no barrier below is workgroup-wide
+    const int64_t row = row0 + g;
+    const bool live_row = row < rows;
+    const T *p = x + (live_row ? row : row0) * red; // groups past the end redo the first row (never stored)
     U key[E];
     unsigned nan = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int j = lane + 64 * e;
-        const T v = j < red ? NFM_LDG(p + j) : T(0);
+        const int jj = j + G * e;
+        const T v = jj < red ? NFM_LDG(p + jj) : T(0);
         key[e] = K::of(v);
-        nan += (j < red && v != v) ? 1u : 0u;
+        nan += (jj < red && v != v) ? 1u : 0u;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nan += __shfl_xor(nan, off, 64);
+    for (int off = G / 2; off > 0; off >>= 1) nan += __shfl_xor(nan, off, G);
     const unsigned count = omitnan ? (unsigned)red - nan : (unsigned)red;
-    U chosen;
-    bool want_nan = false;
-    if ((!omitnan && nan > 0) || count == 0) {
-        chosen = ~U(0);
-        want_nan = true;
-    } else {
-        unsigned long long k = (count - 1) / 2;
-        U prefix = 0;
+    const bool want_nan = (!omitnan && nan > 0) || count == 0;
+    unsigned k = count ? (count - 1) / 2 : 0;
+    U prefix = 0;
 #pragma unroll
-        for (int d = K::digits - 1; d >= 0; --d) {
-            const int shift = 8 * d;
+    for (int d = K::digits - 1; d >= 0; --d) {
+        const int shift = 8 * d;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < NB; ++b) hist[NB * j + b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int j = lane + 64 * e;
-                // elements that agree with the digits chosen so far (all of them in the first pass)
-                const bool in = j < red && above(key[e], d, K::digits) == prefix;
-                if (in) atomicAdd(&hist[(unsigned)(key[e] >> shift) & 255u], 1u);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            unsigned cnt[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) cnt[b] = hist[4 * lane + b];
-            const unsigned digit = pick_digit(cnt, k);
-            prefix = (prefix << 8) | (U)digit;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int e = 0; e < E; ++e) {
+            const int jj = j + G * e;
+            // elements that agree with the digits chosen so far (all of them in the first pass)
+            const bool in = jj < red && above(key[e], d, K::digits) == prefix;
+            if (in) atomicAdd(&hist[(unsigned)(key[e] >> shift) & 255u], 1u);
         }
-        chosen = prefix;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // pick the digit whose cumulative count passes k, inside the group (rows with a NaN result
+        // have no such digit: they go through the motions and are overridden below)
+        unsigned cnt[NB], mine = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            cnt[b] = hist[NB * j + b];
+            mine += cnt[b];
+        }
+        unsigned incl = mine;
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, G);
+            if (j >= off) incl += o;
+        }
+        const unsigned before = incl - mine;
+        const bool here = before <= k && k < before + mine;
+        const unsigned long long gm = (__ballot(here) >> (g * G)) & (G == 64 ? ~0ull : ((1ull << (G % 64)) - 1ull));
+        const int src = gm ? __builtin_ctzll(gm) : G - 1;
+        unsigned digit = 0, kk = k;
+        if (j == src) {
+            unsigned r = k - before, dd = 0;
+#pragma unroll
+            for (int b = 0; b < NB - 1; ++b)
+                if (dd == (unsigned)b && r >= cnt[b]) {
+                    r -= cnt[b];
+                    dd = b + 1;
+                }
+            digit = NB * j + dd;
+            kk = r;
+        }
+        digit = __shfl(digit, src, G);
+        k = __shfl(kk, src, G);
+        prefix = (prefix << 8) | (U)digit;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    const U chosen = want_nan ? ~U(0) : prefix;
     // first position holding the chosen key (a NaN result: the first NaN; all-NaN with omitnan: 0)
     int first = 0x7fffffff;
 #pragma unroll
     for (int e = E - 1; e >= 0; --e) {
-        const int j = lane + 64 * e;
-        if (j < red && key[e] == chosen) first = j;
+        const int jj = j + G * e;
+        if (jj < red && key[e] == chosen) first = jj;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(first, off, 64);
+    for (int off = G / 2; off > 0; off >>= 1) {
+        const int o = __shfl_xor(first, off, G);
         first = o < first ? o : first;
     }
-    if (lane == 0) {
+    if (j == 0 && live_row) {
         val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
         if (idx) idx[row] = first == 0x7fffffff ? 0 : first;
     }
@@ -445,16 +476,19 @@ static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, 
         return launch_status();
     }
     if (red <= kShortMax) {
-        const int64_t nblk = (rows + 3) / 4;
-        if (nblk > 0x7fffffffLL) return NFM_ESIZE;
-#define NFM_MED_ROWS(Ev)                                                                                              \
-    hipLaunchKernelGGL((median_rows_kernel<T, Ev>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const T *>(x), \
-                       rows, (int)red, omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx))
-        if (red <= 64) NFM_MED_ROWS(1);
-        else if (red <= 128) NFM_MED_ROWS(2);
-        else if (red <= 256) NFM_MED_ROWS(4);
-        else if (red <= 512) NFM_MED_ROWS(8);
-        else NFM_MED_ROWS(16);
+#define NFM_MED_ROWS(Ev, Gv)                                                                                          \
+    {                                                                                                                 \
+        const int64_t nblk = (rows + 4 * (64 / Gv) - 1) / (4 * (64 / Gv));                                            \
+        if (nblk > 0x7fffffffLL) return NFM_ESIZE;                                                                    \
+        hipLaunchKernelGGL((median_rows_kernel<T, Ev, Gv>), dim3((unsigned)nblk), dim3(256), 0, s,                    \
+                           static_cast<const T *>(x), rows, (int)red, omitnan, static_cast<T *>(val),                 \
+                           static_cast<int64_t *>(idx));                                                              \
+    }
+        if (red <= 64) NFM_MED_ROWS(4, 16)
+        else if (red <= 128) NFM_MED_ROWS(8, 16)
+        else if (red <= 256) NFM_MED_ROWS(16, 16)
+        else if (red <= 512) NFM_MED_ROWS(16, 32)
+        else NFM_MED_ROWS(16, 64)
 #undef NFM_MED_ROWS
         return launch_status();
     }
