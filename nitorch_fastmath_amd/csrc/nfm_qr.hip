@@ -48,6 +48,11 @@ struct EigSymOp {
     using RO = Rec<1, N + (WITH_U ? N * N : 0)>;
     using Params = QrParams;
     static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
+    // orders >= 5 (and 4 x 4 float64) skip the LDS transpose (op_no_tile): a wavefront's image of their
+    // records held the kernel at 2 waves per SIMD, and from there on eig_sym is bound by its dependent
+    // arithmetic, not by the load rate (same-box A/B: 8x8 with vectors 1.5x / 1.7x faster in float32 /
+    // float64, 6x6 1.1-1.4x, 4x4 float64 1.02-1.09x; 3x3 and 4x4 float32 are better off tiled)
+    static constexpr bool kNoTile = N >= 5 || (N == 4 && sizeof(T) == 8);
     static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
                                                  T (&o)[RO::Cs], const Params &p)
     {

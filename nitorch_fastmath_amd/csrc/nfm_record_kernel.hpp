@@ -265,6 +265,14 @@ struct op_streams : std::false_type {};
 template <class Op>
 struct op_streams<Op, std::void_t<decltype(Op::kStream)>> : std::bool_constant<Op::kStream> {};
 
+// Ops that define `static constexpr bool kNoTile = true` never stage their records through LDS: their
+// LDS image (a wavefront's worth of large records) would bound the occupancy of a kernel that is bound by
+// its arithmetic, not by the load rate -- each lane fetches its record with packed 16-byte accesses.
+template <class Op, class = void>
+struct op_no_tile : std::false_type {};
+template <class Op>
+struct op_no_tile<Op, std::void_t<decltype(Op::kNoTile)>> : std::bool_constant<Op::kNoTile> {};
+
 // KIND_AOS = every operand is a contiguous batch-major block (the default torch layout):
 // the movement mode of each operand is then a compile-time constant (packed access for
 // 4/8/16-byte records, LDS transpose for the rest), which removes every mode branch and
@@ -479,10 +487,11 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     // movement mode of every operand for a batch of n records starting at the given pointers
     auto classify = [&](const nfm_operand *pa, const nfm_operand *pb, const nfm_operand *pc,
                         const nfm_operand *po, int64_t n) {
-        const bool ta = L::A::can_tile && tile_ok(pa, RA::C, RA::R, RA::Cc, n_outer, n, sizeof(T));
-        const bool tb = L::B::can_tile && tile_ok(pb, RB::C, RB::R, RB::Cc, n_outer, n, sizeof(T));
-        const bool tc = L::C::can_tile && tile_ok(pc, RC::C, RC::R, RC::Cc, n_outer, n, sizeof(T));
-        const bool to = L::O::can_tile && tile_ok(po, RO::C, RO::R, RO::Cc, n_outer, n, sizeof(T));
+        constexpr bool tiles = !op_no_tile<Op>::value;
+        const bool ta = tiles && L::A::can_tile && tile_ok(pa, RA::C, RA::R, RA::Cc, n_outer, n, sizeof(T));
+        const bool tb = tiles && L::B::can_tile && tile_ok(pb, RB::C, RB::R, RB::Cc, n_outer, n, sizeof(T));
+        const bool tc = tiles && L::C::can_tile && tile_ok(pc, RC::C, RC::R, RC::Cc, n_outer, n, sizeof(T));
+        const bool to = tiles && L::O::can_tile && tile_ok(po, RO::C, RO::R, RO::Cc, n_outer, n, sizeof(T));
         auto mode = [&](bool tiled, bool can_vec, bool can_soa, const nfm_operand *op, int C, int R, int Cc,
                         bool input) {
             if (tiled) return (int)MODE_TILED;
