@@ -273,6 +273,13 @@ struct op_no_tile : std::false_type {};
 template <class Op>
 struct op_no_tile<Op, std::void_t<decltype(Op::kNoTile)>> : std::bool_constant<Op::kNoTile> {};
 
+// mode of an operand in the compile-time (KIND_AOS) kernel: its preferred one, or for a no-tile Op the
+// packed per-lane access wherever the preferred one is the LDS tile
+template <class Op, class IO>
+struct aos_mode {
+    static constexpr int value = (op_no_tile<Op>::value && IO::pref == MODE_TILED) ? (int)MODE_PACKED : IO::pref;
+};
+
 // KIND_AOS = every operand is a contiguous batch-major block (the default torch layout):
 // the movement mode of each operand is then a compile-time constant (packed access for
 // 4/8/16-byte records, LDS transpose for the rest), which removes every mode branch and
@@ -341,10 +348,10 @@ __global__ __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opn
     // LDS regions and movement modes: compile-time constants in the FAST kernel
     constexpr int oA = FAST ? L::offA : L::gA, oB = FAST ? L::offB : L::gB;
     constexpr int oC = FAST ? L::offC : L::gC, oO = FAST ? L::offO : L::gO;
-    const int ma = FAST ? IA::pref : (SFAST ? IA::pref_soa : a.tiled);
-    const int mb = FAST ? IB::pref : (SFAST ? IB::pref_soa : b.tiled);
-    const int mc = FAST ? IC::pref : (SFAST ? IC::pref_soa : c.tiled);
-    const int mo = FAST ? IO_::pref : (SFAST ? IO_::pref_soa : out.tiled);
+    const int ma = FAST ? aos_mode<Op, IA>::value : (SFAST ? IA::pref_soa : a.tiled);
+    const int mb = FAST ? aos_mode<Op, IB>::value : (SFAST ? IB::pref_soa : b.tiled);
+    const int mc = FAST ? aos_mode<Op, IC>::value : (SFAST ? IC::pref_soa : c.tiled);
+    const int mo = FAST ? aos_mode<Op, IO_>::value : (SFAST ? IO_::pref_soa : out.tiled);
     const bool use_c = RC::used && c.ptr != nullptr;
     const bool tA = IA::can_tile && ma == MODE_TILED, tB = IB::can_tile && mb == MODE_TILED;
     const bool tC = IC::can_tile && mc == MODE_TILED && use_c, tO = IO_::can_tile && mo == MODE_TILED;
@@ -510,8 +517,18 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
         m.any = ta || tb || tc || to || m.ma == MODE_SOA || m.mb == MODE_SOA || m.mc == MODE_SOA ||
                 m.mo == MODE_SOA;
         // FAST path: every used operand in its preferred mode (an absent C operand is fine)
-        m.fast = n_outer == 1 && (!RA::used || m.ma == L::A::pref) && (!RB::used || m.mb == L::B::pref) &&
-                 (!RC::used || c_absent || m.mc == L::C::pref) && m.mo == L::O::pref &&
+        // (for a no-tile Op a packed operand must also be what the tile would have taken: contiguous
+        // back-to-back records -- the compile-time kernel computes addresses from the record size)
+        auto want = [&](int pref, int nt_mode, const nfm_operand *op, int C, int R, int Cc, int got) {
+            if (nt_mode == pref) return got == pref;
+            return got == nt_mode && tile_ok(op, C, R, Cc, n_outer, n, sizeof(T));
+        };
+        m.fast = n_outer == 1 &&
+                 (!RA::used || want(L::A::pref, aos_mode<Op, typename L::A>::value, pa, RA::C, RA::R, RA::Cc, m.ma)) &&
+                 (!RB::used || want(L::B::pref, aos_mode<Op, typename L::B>::value, pb, RB::C, RB::R, RB::Cc, m.mb)) &&
+                 (!RC::used || c_absent ||
+                  want(L::C::pref, aos_mode<Op, typename L::C>::value, pc, RC::C, RC::R, RC::Cc, m.mc)) &&
+                 want(L::O::pref, aos_mode<Op, typename L::O>::value, po, RO::C, RO::R, RO::Cc, m.mo) &&
                  L::A::pref != MODE_STRIDED && L::O::pref != MODE_STRIDED &&
                  (!RB::used || L::B::pref != MODE_STRIDED) && (!RC::used || L::C::pref != MODE_STRIDED);
         return m;
@@ -528,7 +545,7 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
     const size_t lds = any ? (size_t)L::gtotal : 0;
     // > 64 KiB of dynamic LDS: opt-in per kernel and per device (lds_opt_in, nfm_common.hpp)
     if (fast) {
-        if (LF::total > 64 * 1024) {
+        if (!op_no_tile<Op>::value && LF::total > 64 * 1024) {
             static std::atomic<uint64_t> have_aos{0};
             const int rc = lds_opt_in(have_aos, reinterpret_cast<const void *>(&rec_kernel<T, Op, KIND_AOS>), LF::total);
             if (rc != NFM_OK) return rc;
@@ -543,7 +560,7 @@ int rec_launch(const nfm_operand *a, const nfm_operand *b, const nfm_operand *c,
         }
     }
     if (fast) {
-        hipLaunchKernelGGL((rec_kernel<T, Op, KIND_AOS>), grid, block, (size_t)LF::total,
+        hipLaunchKernelGGL((rec_kernel<T, Op, KIND_AOS>), grid, block, op_no_tile<Op>::value ? (size_t)0 : (size_t)LF::total,
                            static_cast<hipStream_t>(stream), make_opnd(a, ma), make_opnd(b, mb), make_opnd(c, mc),
                            make_opnd(out, mo), n_inner, prm);
     } else {
