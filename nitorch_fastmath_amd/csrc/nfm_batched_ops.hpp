@@ -96,6 +96,7 @@ struct BatchDetOp {
     using RO = Rec<1, 1>;
     using Params = NoParamsB;
     static constexpr int TILE = pick_tile(RA::C * (int)sizeof(T) + 16);
+    static constexpr bool kNoTile = large_no_tile(sizeof(T) == 8, N, LN_BDET);
     static __device__ __forceinline__ void apply(const T (&a)[RA::Cs], const T (&)[1], const T (&)[1], T (&r)[1],
                                                  const Params &)
     {

@@ -273,6 +273,25 @@ struct op_no_tile : std::false_type {};
 template <class Op>
 struct op_no_tile<Op, std::void_t<decltype(Op::kNoTile)>> : std::bool_constant<Op::kNoTile> {};
 
+// Orders 9..16, one matrix per lane: which kernels fetch their records per lane instead of through the LDS
+// transpose (op_no_tile, nfm_record_kernel.hpp).  Without the LDS image some of them gain a wavefront per
+// SIMD (12x12 float32 solve: 257 -> 254 VGPRs, 1 -> 2 waves: 1.6x), others lose the coalescing for nothing;
+// measured case by case on one box with two builds of the library (scripts/gpu_ab_large.sh,
+// profiles/r02/large_no_tile_ab.md) -- the cases where the no-tile build won by more than 5 %.
+enum { LN_SOLVE = 0, LN_DET = 1, LN_BDET = 2 };
+__host__ __device__ constexpr bool large_no_tile(bool f64, int N, int what)
+{
+    if (N < 9) return false;
+    if (!f64) {
+        if (what == LN_SOLVE) return N >= 10 && N <= 14;
+        if (what == LN_DET) return N <= 15;
+        return N >= 12 && N <= 15; // LN_BDET
+    }
+    if (what == LN_SOLVE) return N <= 10;
+    if (what == LN_DET) return N >= 10 && N <= 13;
+    return N >= 10 && N <= 12; // LN_BDET
+}
+
 // mode of an operand in the compile-time (KIND_AOS) kernel: its preferred one, or for a no-tile Op the
 // packed per-lane access wherever the preferred one is the LDS tile
 template <class Op, class IO>

@@ -32,6 +32,7 @@ struct SolveOp {
     // contiguous 4x4 / 6x6 fp32 systems (configurations C2 / C5): 512-lane tiles, +2-4 % in same-box
     // A/B runs at 1e8 systems (see KindTile); the other orders measured flat within run-to-run noise
     static constexpr int kAosTile = ((M == 4 || M == 6) && KIND == NFM_MAT_SYM && sizeof(T) == 4) ? 512 : TILE;
+    static constexpr bool kNoTile = KIND == NFM_MAT_SYM && large_no_tile(sizeof(T) == 8, M, LN_SOLVE);
     static __device__ __forceinline__ void apply(T (&a)[RA::Cs], const T (&v)[M], const T (&)[1], T (&x)[M],
                                                  const Params &p)
     {
@@ -163,6 +164,7 @@ struct DetOp {
     using RO = Rec<1, 1>;
     using Params = NoParams;
     static constexpr int TILE = pick_tile(RA::C * (int)sizeof(T) + 16);
+    static constexpr bool kNoTile = large_no_tile(sizeof(T) == 8, M, LN_DET);
     static __device__ __forceinline__ void apply(const T (&a)[RA::Cs], const T (&)[1], const T (&)[1], T (&r)[1],
                                                  const Params &)
     {
