@@ -111,6 +111,9 @@ struct QrHessOp {
     using RO = Rec<1, 2 * N * N>;
     using Params = QrParams;
     static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
+    // 8 x 8 float64: 1.5 KiB of records per lane, i.e. a 96 KiB LDS image per 64-lane workgroup and one
+    // wavefront per CU -- fetched and stored per lane instead (op_no_tile)
+    static constexpr bool kNoTile = (RA::C + RO::C) * (int)sizeof(T) >= 1400;
     static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
                                                  T (&o)[RO::Cs], const Params &)
     {
