@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define NFM_VERSION 3 /* 2: nfm_qr_eig_sym takes flags (NFM_EIG_*); nfm_reduce_median added; 3: nfm_reduce_median_mid */
+#define NFM_VERSION 4 /* 2: nfm_qr_eig_sym takes flags (NFM_EIG_*); nfm_reduce_median added; 3: nfm_reduce_median_mid;
+                         4: nfm_qr_eig_sym flags: bit 2 is NFM_EIG_FAST (flags == with_u is the reference order again) */
 #define NFM_MAX_DIM 16 /* largest matrix order handled (3x3 .. 16x16 and below) */
 
 /* dtype codes */
@@ -283,19 +284,20 @@ int nfm_qr_rq_hessenberg(int dtype, int N, int sym, int64_t n_outer, int64_t n_i
  * `_fwd_eig_sym` `_impl/qr.py:665-681`.  Convergence is judged per matrix with the
  * reference's criterion (quirk Q9).  out record: [vals (N) | NFM_EIG_VECTORS: vecs (N*N
  * row-major, eigenvectors in columns)].
- * flags: NFM_EIG_VECTORS        also compute the eigenvectors (`compute_u`);
- *        NFM_EIG_REFERENCE_ORDER run the QR sweeps in the reference's operation order with IEEE
- *                                division / square root -- bit-identical to the CPU restatement
- *                                (same deflation order, same eigenvector signs) at a third to a
- *                                quarter of the throughput.  Without it the sweeps use v_rsq +
- *                                Newton steps (one for float32, two for float64) and fma
- *                                contraction, the last 2x2 block is diagonalised by one Jacobi
- *                                rotation, and `tol` is floored at the working precision of the
- *                                dtype, max(tol, (eps/4)^2): as accurate against the exact
- *                                eigenvalues, but order and signs may differ (both are
- *                                unspecified by the reference: `qr.py:45-46`). */
+ * flags: NFM_EIG_VECTORS  also compute the eigenvectors (`compute_u`); flags == 0 / 1 is exactly the
+ *                          reference's `compute_u` argument and selects the reference's arithmetic:
+ *                          its operation order, its tolerance, correctly rounded division and
+ *                          square root -- bit-identical to the CPU restatement (same deflation
+ *                          order, same eigenvector signs).
+ *        NFM_EIG_FAST     opt-in: the sweeps use v_rsq + Newton steps (one for float32, two for
+ *                          float64) and fma contraction, the last 2x2 block is diagonalised by one
+ *                          Jacobi rotation, and `tol` is floored at the working precision of the
+ *                          dtype, max(tol, (eps/4)^2): as accurate against the exact eigenvalues
+ *                          and 2-3x the throughput, but the deflation ORDER and the eigenvector
+ *                          SIGNS differ from the reference's for a share of the matrices (float32:
+ *                          2 % at 3x3, 35 % at 8x8) and float32 values by up to 1.4e-6. */
 #define NFM_EIG_VECTORS 1
-#define NFM_EIG_REFERENCE_ORDER 2
+#define NFM_EIG_FAST 2
 int nfm_qr_eig_sym(int dtype, int N, int upper, int flags, int max_iter, double tol,
                    int64_t n_outer, int64_t n_inner, const nfm_operand *a, void *out, void *stream);
 

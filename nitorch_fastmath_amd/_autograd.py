@@ -129,7 +129,7 @@ class EigSymFn(torch.autograd.Function):
     A_bar = U (diag(D_bar) + F o (U^T U_bar)) U^T, F_ij = 1 / (d_j - d_i), F_ii = 0."""
 
     @staticmethod
-    def forward(ctx, a, compute_u, upper, max_iter, tol, arithmetic='fast'):
+    def forward(ctx, a, compute_u, upper, max_iter, tol, arithmetic='reference'):
         from . import qr
         val, vec = qr.eig_sym(a, compute_u=True, upper=upper, check_finite=False, max_iter=max_iter, tol=tol,
                               arithmetic=arithmetic)

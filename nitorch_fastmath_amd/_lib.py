@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('NFM_HIP_LIB') or os.path.join(_HERE, 'libnfm_hip.so')
 F32, F64 = 0, 1
 MAT_SYM, MAT_DIAG, MAT_SCAL, MAT_FULL = 0, 1, 2, 3
 FLAG_TS_PERTURB = 1
-EIG_VECTORS, EIG_REFERENCE_ORDER = 1, 2      # flags of nfm_qr_eig_sym
+EIG_VECTORS, EIG_FAST = 1, 2                 # flags of nfm_qr_eig_sym
 RED_NANSUM, RED_NANMAX, RED_NANMIN, RED_SUM, RED_MAX, RED_MIN, RED_NANCOUNT, RED_NANSUMSQ = range(8)
 MAX_DIM = 16
 SIDE = {'left': 0, 'right': 1, 'both': 2}

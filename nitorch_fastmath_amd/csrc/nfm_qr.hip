@@ -574,8 +574,8 @@ int nfm_qr_eig_sym(int dtype, int N, int upper, int flags, int max_iter, double 
                    int64_t n_inner, const nfm_operand *a, void *out, void *stream)
 {
     QR_COMMON_CHECKS(N)
-    if (max_iter < 0 || flags < 0 || flags > (NFM_EIG_VECTORS | NFM_EIG_REFERENCE_ORDER)) return NFM_EINVAL;
-    const int with_u = (flags & NFM_EIG_VECTORS) != 0, fast = (flags & NFM_EIG_REFERENCE_ORDER) == 0;
+    if (max_iter < 0 || flags < 0 || flags > (NFM_EIG_VECTORS | NFM_EIG_FAST)) return NFM_EINVAL;
+    const int with_u = (flags & NFM_EIG_VECTORS) != 0, fast = (flags & NFM_EIG_FAST) != 0;
     if ((rc = check_operand(a, dtype, nonempty))) return rc;
     if (nonempty && out == nullptr) return NFM_EINVAL;
     QrParams p = mkparams(N, upper ? 1 : 0, 1, 0, max_iter, tol);

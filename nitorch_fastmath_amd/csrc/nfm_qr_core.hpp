@@ -102,6 +102,119 @@ struct FastRange<double> {
     static constexpr double lo = 0x1p-900, hi = 0x1p900;
 };
 
+// ---------------------------------------------------------------------------------------
+// Correctly rounded division and square root WITHOUT their range handling: what eig_sym's
+// reference-order arithmetic (FAST = false: the default, bit-identical to the CPU restatement) runs.
+//
+// hipcc's IEEE sequences are, for float32: division = 2 v_div_scale + v_rcp + 2 fma (reciprocal) +
+// mul + 3 fma + v_div_fmas + v_div_fixup (11 instructions), square root = scale-up select, v_sqrt,
+// two neighbours tested with one fma each, scale-down select, class select (16); float64: 11 and 20.
+// v_div_scale / v_div_fixup and the scaling selects only act on operands near the ends of the exponent
+// range (denormals, quotients that underflow, zeros, inf, NaN).  For operands inside the ranges of
+// `CrRange` they are the identity, and what is left is the SAME arithmetic -- so the same correctly
+// rounded bits -- in 8 (one division), 3 + 5 per numerator (a shared denominator; the numerator part
+// packs to v_pk_* for float32) and 9 / 10 (square root) instructions.  Whether every active lane of
+// the wavefront is inside the ranges is one vote per rotation / shift (`__any`: a uniform branch, no
+// exec-mask juggling on the common path); otherwise the whole wavefront runs hipcc's full sequences,
+// whose result for the in-range lanes is the same by construction.
+// Ranges (a lane outside them is correct, just slower): squared norms / sqrt arguments in
+// [2^-96, 2^40] (float64: [2^-760, 2^120]) -- denominators in [2^-48, 2^20] -- and numerators of
+// magnitude >= 2^-102 (2^-960): no operand or quotient is denormal, no residual fma loses bits
+// (v_div_scale's own criterion: numerator exponent > 23 / 52), exponent differences stay below 96 / 768.
+// Zero numerators take the full sequence too (the trimmed one returns +0 for -0 / n).
+template <typename T>
+struct CrRange;
+template <>
+struct CrRange<float> {
+    static constexpr float r2_lo = 0x1p-96f, r2_hi = 0x1p40f, num_lo = 0x1p-102f;
+};
+template <>
+struct CrRange<double> {
+    static constexpr double r2_lo = 0x1p-760, r2_hi = 0x1p120, num_lo = 0x1p-960;
+};
+template <typename T>
+using V2 = T __attribute__((ext_vector_type(2)));
+
+// lo <= x <= hi for x >= 0 as ONE unsigned compare of the (high) dword; NaN, inf and negative values fail
+__device__ __forceinline__ bool cr_in_range(float x)
+{
+    constexpr unsigned lo = 0x0f800000u /* 2^-96 */, hi = 0x53800000u /* 2^40 */;
+    static_assert(CrRange<float>::r2_lo == 0x1p-96f && CrRange<float>::r2_hi == 0x1p40f, "bit patterns above");
+    return (__builtin_bit_cast(unsigned, x) - lo) <= (hi - lo);
+}
+__device__ __forceinline__ bool cr_in_range(double x)
+{
+    constexpr unsigned lo = (1023u - 760u) << 20, hi = (1023u + 120u) << 20;
+    static_assert(CrRange<double>::r2_lo == 0x1p-760 && CrRange<double>::r2_hi == 0x1p120, "bit patterns above");
+    return ((unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32) - lo) <= (hi - lo);
+}
+
+// sqrt: hipcc's float32 sequence without the 2^32 scaling of arguments below 2^-96 and the class select
+__device__ __forceinline__ float sqrt_cr(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x); // <= 1 ulp
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    float r = (rd <= 0.0f) ? sd : s;
+    r = (ru > 0.0f) ? su : r;
+    return r;
+}
+// ... and the float64 one (v_rsq_f64 + a coupled Newton step + two residual corrections) without its ldexp pair
+__device__ __forceinline__ double sqrt_cr(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+// refined reciprocal of the (shared) denominator: v_rcp + one (float64: two) Newton steps, as in hipcc's division
+__device__ __forceinline__ float rcp_cr(float n)
+{
+    const float r = __builtin_amdgcn_rcpf(n);
+    return __builtin_fmaf(__builtin_fmaf(-n, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double rcp_cr(double n)
+{
+    double r = __builtin_amdgcn_rcp(n);
+    r = __builtin_fma(r, __builtin_fma(-n, r, 1.0), r);
+    return __builtin_fma(r, __builtin_fma(-n, r, 1.0), r);
+}
+// x / n given r = rcp_cr(n): quotient, residual, correction (float32: twice), the last fma is v_div_fmas unscaled
+__device__ __forceinline__ float div_cr(float x, float n, float r)
+{
+    float q = x * r;
+    q = __builtin_fmaf(__builtin_fmaf(-n, q, x), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-n, q, x), r, q);
+}
+__device__ __forceinline__ double div_cr(double x, double n, double r)
+{
+    const double q = x * r;
+    return __builtin_fma(__builtin_fma(-n, q, x), r, q);
+}
+// (x, y) / n: the same steps on a register pair -- v_pk_mul_f32 / v_pk_fma_f32 for float32
+__device__ __forceinline__ void div2_cr(float x, float y, float n, float &qx, float &qy)
+{
+    const float r = rcp_cr(n);
+    const V2<float> xy = {x, y}, nn = {-n, -n}, rr = {r, r};
+    V2<float> q = xy * rr;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nn, q, xy), rr, q);
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nn, q, xy), rr, q);
+    qx = q.x;
+    qy = q.y;
+}
+__device__ __forceinline__ void div2_cr(double x, double y, double n, double &qx, double &qy)
+{
+    const double r = rcp_cr(n);
+    qx = div_cr(x, n, r);
+    qy = div_cr(y, n, r);
+}
+
 // _givens_jit :326-334
 template <typename T>
 __device__ __forceinline__ void givens1(T x, T y, T &c, T &s);
@@ -157,9 +270,48 @@ __device__ __forceinline__ void rot1(T &a0, T &a1, T c, T s)
     a1 = a1 * c + tmp;
 }
 
+// givens1 for eig_sym's reference-order sweeps: the same bits; the trimmed sequences when every active lane is in range
+template <typename T>
+__device__ __forceinline__ void givens_cr1(T x, T y, T &c, T &s)
+{
+#pragma clang fp contract(off)
+    const T r2 = x * x + y * y;
+    const T lo = fabs_(x) < fabs_(y) ? fabs_(x) : fabs_(y);
+    const bool ok = cr_in_range(r2) && lo >= CrRange<T>::num_lo;
+    if (__builtin_expect(__any(!ok), 0)) {
+        givens1<T>(x, y, c, s);
+        return;
+    }
+    const T nrm = sqrt_cr(r2);
+    T sy;
+    div2_cr(x, y, nrm, c, sy);
+    s = -sy;
+}
+
+// rot1 on a register pair (a0, a1) <- (a0 c - s a1, a1 c + s a0).  float32: two v_pk_mul_f32 and one
+// v_pk_add_f32 that swaps the halves of its second operand and negates the one added to the low half
+// (op_sel / neg_lo) -- separately rounded products and sums, the same bits as rot1.
+template <typename T>
+__device__ __forceinline__ void rot_pair1(T &a0, T &a1, T c, T s)
+{
+#pragma clang fp contract(off)
+    if constexpr (sizeof(T) == 4) {
+        const V2<float> v = {a0, a1};
+        const V2<float> t = v * s, w = v * c;
+        V2<float> o;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(w), "v"(t));
+        a0 = o.x;
+        a1 = o.y;
+    } else {
+        rot1(a0, a1, c, s);
+    }
+}
+
 // householder_ :55-69 on x[0..m), reflecting onto component `basis` (compile-time or not;
 // the element is picked by a select so that registers are never indexed dynamically)
-template <typename T, int NT, bool FAST = false>
+// TRIM (eig_sym's reference-order arithmetic): the two square roots and the m divisions run the trimmed
+// correctly rounded sequences (CrRange above) when every active lane is in range -- the same bits
+template <typename T, int NT, bool FAST = false, bool TRIM = false>
 __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis)
 {
 #pragma clang fp contract(off)
@@ -203,6 +355,30 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
         for (int i = 0; i < Dim<NT>::MAX; ++i)
             if (i < m) x[i] = ((i == basis) ? x[i] - rhof : x[i]) * inv;
         return rhof;
+    }
+    if constexpr (TRIM) {
+        // in range: ss (and the second sum of squares, <= 4 ss) a valid sqrt argument / denominator, every
+        // component a valid numerator (the reflected one becomes |x_b| + |x| >= the denominator's floor)
+        T lo = fabs_(x[0]);
+#pragma unroll
+        for (int i = 1; i < Dim<NT>::MAX; ++i)
+            if (i < m) lo = fabs_(x[i]) < lo ? fabs_(x[i]) : lo;
+        const bool ok = cr_in_range(ss * T(4)) && cr_in_range(ss) && lo >= CrRange<T>::num_lo;
+        if (!__builtin_expect(__any(!ok), 0)) {
+            rho *= sqrt_cr(ss);
+#pragma unroll
+            for (int i = 0; i < Dim<NT>::MAX; ++i)
+                if (i < m) x[i] = (i == basis) ? x[i] - rho : x[i];
+            ss = T(0);
+#pragma unroll
+            for (int i = 0; i < Dim<NT>::MAX; ++i)
+                if (i < m) ss += x[i] * x[i];
+            const T nrm = sqrt_cr(ss), rn = rcp_cr(nrm);
+#pragma unroll
+            for (int i = 0; i < Dim<NT>::MAX; ++i)
+                if (i < m) x[i] = div_cr(x[i], nrm, rn);
+            return rho;
+        }
     }
     rho *= sqrt_(ss);
 #pragma unroll
@@ -276,7 +452,7 @@ __device__ __forceinline__ void hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], 
 // hessenberg_sym_lower_ :296-323 on a matrix whose LOWER triangle holds the data (the
 // caller mirrors the requested triangle on load, which is what the reference's transposed
 // view does for upper=True).  Output: symmetric tridiagonal, both halves filled.
-template <typename T, int NT, bool WITH_U, bool FAST = false>
+template <typename T, int NT, bool WITH_U, bool FAST = false, bool TRIM = false>
 __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n,
                                                 T (&up)[Dim<NT>::MAX][Dim<NT>::MAX])
 {
@@ -290,7 +466,7 @@ __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MA
 #pragma unroll
             for (int r = 0; r < MX; ++r)
                 if (r < m) u[r] = a[o + r][k];
-            const T alpha = householder1<T, NT, FAST>(u, m, 0);
+            const T alpha = householder1<T, NT, FAST, TRIM>(u, m, 0);
             if (WITH_U) {
 #pragma unroll
                 for (int r = 0; r < MX; ++r)
@@ -439,6 +615,52 @@ __device__ __forceinline__ T wilkinson1(T h0, T h1, T b)
     return h1 - s * b2 / d;
 }
 
+// wilkinson1 with the trimmed sequences on a vote (same bits)
+template <typename T>
+__device__ __forceinline__ T wilkinson_cr1(T h0, T h1, T b)
+{
+#pragma clang fp contract(off)
+    const T b2 = b * b;
+    const T d = (h0 - h1) * T(0.5); // == / 2, exactly
+    const T t = d * d + b2;
+    const bool ok = cr_in_range(t) && b2 >= CrRange<T>::num_lo;
+    if (__builtin_expect(__any(!ok), 0)) return wilkinson1<T>(h0, h1, b);
+    const T den = fabs_(d) + sqrt_cr(t); // > 0 in range
+    const T sb2 = (d < T(0)) ? -b2 : b2;
+    return h1 - div_cr(sb2, den, rcp_cr(den));
+}
+
+// rq_step1(..., sym = true) of eig_sym's reference-order sweeps: the same operations on the same
+// entries (the tridiagonal shortcut of _rq_hessenberg_jit_ :457-485), rotations by givens_cr1 / rot_pair1
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void rq_step_cr1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                            int n, int m)
+{
+    constexpr int MX = Dim<NT>::MAX;
+    T lc[MX], ls[MX];
+#pragma unroll
+    for (int k = 0; k < MX - 1; ++k) {
+        if (k < m - 1) {
+            givens_cr1(a[k][k], a[k + 1][k], lc[k], ls[k]);
+#pragma unroll
+            for (int j = k; j < MX && j < k + 3; ++j)
+                if (j < m) rot_pair1(a[k][j], a[k + 1][j], lc[k], ls[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MX - 1; ++k) {
+        if (k < m - 1) {
+#pragma unroll
+            for (int i = (k > 0 ? k - 1 : 0); i < k + 2; ++i) rot_pair1(a[i][k], a[i][k + 1], lc[k], ls[k]);
+            if (WITH_U) {
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < n) rot_pair1(u[i][k], u[i][k + 1], lc[k], ls[k]);
+            }
+        }
+    }
+}
+
 // the same shift for the fast sweeps: hardware sqrt / rcp (a shift only steers the iteration)
 template <typename T>
 __device__ __forceinline__ T wilkinson_fast1(T h0, T h1, T b)
@@ -564,6 +786,8 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
         tol = tol > floor_ ? tol : floor_;
     }
     const T tol_t = (T)tol, stuck_t = (T)(tol * 1e-3);
+    // the exact "stuck" test can be screened by an estimate when its threshold is below half an ulp of T
+    const bool screen_stuck = tol * 1e-3 < (sizeof(T) == 4 ? 0x1p-25 : 0x1p-54);
     if (WITH_U) {
 #pragma unroll
         for (int i = 0; i < MX; ++i)
@@ -579,17 +803,17 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                     if (jacobi2_fast1<T, NT, WITH_U>(h, u, n)) iters = 0;
             }
             double sos_prev = 0.0;
-            T ratio_prev = T(0);
+            T ratio_prev = T(0), low_prev = T(0), diag_prev = T(1);
             for (int it = 0; it < iters; ++it) {
                 T sigma;
                 if constexpr (FM) sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
-                else sigma = wilkinson1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
+                else sigma = wilkinson_cr1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
                 if constexpr (FM) {
                     tri_sweep_fast1<T, NT, WITH_U>(h, u, n, m, sigma);
                 } else {
 #pragma unroll
                     for (int i = 0; i < m; ++i) h[i][i] -= sigma;
-                    rq_step1<T, NT, WITH_U, false>(h, u, n, m, true);
+                    rq_step_cr1<T, NT, WITH_U>(h, u, n, m);
 #pragma unroll
                     for (int i = 0; i < m; ++i) h[i][i] += sigma;
                 }
@@ -612,14 +836,30 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
                     if (ratio_prev != T(0) && dif < stuck_t * ratio_prev) break;
                     ratio_prev = ratio;
                 } else if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
-                    // |prev - new| / prev < tol * 1e-3, written without the fp64 division (prev > 0)
-                    double sos_new;
-                    if constexpr (FM) // the ratio only detects a fixed point of the iteration
-                        sos_new = (double)(sos_lower * hw_rcp(sos_diag));
-                    else sos_new = (double)(sos_lower / sos_diag);
-                    const double dif = sos_prev - sos_new;
-                    if (sos_prev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sos_prev) break;
-                    sos_prev = sos_new;
+                    // |prev - new| / prev < tol * 1e-3 with new = sos_lower / sos_diag correctly rounded in T,
+                    // written without the fp64 division (prev > 0).  Below a relative threshold of one ulp of T
+                    // the exit can only fire when the two quotients are EQUAL, so the division itself is only
+                    // run when an estimate (v_rcp: a few ulp) says they may be: a wavefront vote, the
+                    // reference's decision bit for bit either way.
+                    if (screen_stuck) {
+                        const T ratio = sos_lower * hw_rcp(sos_diag);
+                        const bool far = fabs_(ratio - ratio_prev) > ratio_prev * T(0x1p-18); // NaN / inf: not far
+                        const T lp = low_prev, dp = diag_prev;
+                        ratio_prev = ratio;
+                        low_prev = sos_lower;
+                        diag_prev = sos_diag;
+                        if (__builtin_expect(__any(!far), 0)) {
+                            const double snew = (double)(sos_lower / sos_diag);
+                            const double sprev = it > 0 ? (double)(lp / dp) : 0.0;
+                            const double dif = sprev - snew;
+                            if (!far && sprev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sprev) break;
+                        }
+                    } else {
+                        const double sos_new = (double)(sos_lower / sos_diag);
+                        const double dif = sos_prev - sos_new;
+                        if (sos_prev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sos_prev) break;
+                        sos_prev = sos_new;
+                    }
                 }
             }
         }
@@ -671,7 +911,7 @@ __device__ __forceinline__ void eig_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (
 {
     constexpr int MX = Dim<NT>::MAX;
     T up[MX][MX];
-    hessenberg_sym1<T, NT, WITH_U, FAST>(a, n, up);
+    hessenberg_sym1<T, NT, WITH_U, FAST, !FAST>(a, n, up);
     qr_explicit1<T, NT, WITH_U, FAST>(a, u, n, max_iter, tol);
     if (WITH_U) {
         // householder_apply_(u, q, side='left', inverse=True): reflectors in reverse order

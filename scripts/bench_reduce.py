@@ -67,12 +67,12 @@ if 'qr' in which:
             H = torch.triu(A, -1)
             rows.append((f'qr_hessenberg {M}x{M} {dn}', n, 3 * M * M * sz, timeit(lambda: N.qr_hessenberg(H, check_finite=False))))
             rows.append((f'rq_hessenberg {M}x{M} {dn}', n, 2 * M * M * sz, timeit(lambda: N.rq_hessenberg(H, check_finite=False))))
-            rows.append((f'eig_sym {M}x{M} {dn} values', n, (M * M + M) * sz,
-                         timeit(lambda: N.eig_sym(S, check_finite=False), reps=3)))
-            rows.append((f'eig_sym {M}x{M} {dn} vectors', n, (2 * M * M + M) * sz,
-                         timeit(lambda: N.eig_sym(S, compute_u=True, check_finite=False), reps=3)))
-            rows.append((f"eig_sym {M}x{M} {dn} values, arithmetic='reference'", n, (M * M + M) * sz,
-                         timeit(lambda: N.eig_sym(S, check_finite=False, arithmetic='reference'), reps=3)))
+            for mode in ('reference', 'fast'):      # 'reference' is the default (bit-identical to the CPU path)
+                lab = '' if mode == 'reference' else ", arithmetic='fast'"
+                rows.append((f'eig_sym {M}x{M} {dn} values{lab}', n, (M * M + M) * sz,
+                             timeit(lambda: N.eig_sym(S, check_finite=False, arithmetic=mode), reps=3)))
+                rows.append((f'eig_sym {M}x{M} {dn} vectors{lab}', n, (2 * M * M + M) * sz,
+                             timeit(lambda: N.eig_sym(S, compute_u=True, check_finite=False, arithmetic=mode), reps=3)))
             del A, S, v, H
 print('| op | units | B/unit | ms | units/s | GB/s | frac of 8 TB/s |')
 print('|---|---|---|---|---|---|---|')

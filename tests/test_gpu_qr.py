@@ -28,7 +28,7 @@ class GpuQ:
     """the QR family on the GPU behind the oracle's call shapes (numpy in, numpy out), so that
     the golden cases of tests/test_oracle_golden.py run unchanged against the kernels"""
 
-    def __init__(self, dev, arithmetic='reference'):
+    def __init__(self, dev, arithmetic=None):      # None: the library's default (= 'reference')
         self.dev, self.arithmetic = dev, arithmetic
 
     def t(self, x):
@@ -111,7 +111,8 @@ def test_golden_sym_family(dev, golden_qr, dn, n):
     """orders where the reference itself runs: TOL (1e-6 / 1e-12), no scaling.  The reference-order
     arithmetic reproduces the deflation ORDER and the eigenvector SIGNS of the reference."""
     g, k, tol = golden_qr, f'{dn}_n{n}_', TOL[dn]
-    G = GpuQ(dev, 'reference')
+    assert Q().SWEEP_ARITHMETIC == 'reference'
+    G = GpuQ(dev)                                  # the DEFAULT arithmetic holds the golden order and signs
     a, sym = g[k + 'a'], g[k + 'sym']
     for up in (1, 0):
         tt, us = G.hessenberg_sym(sym, upper=bool(up), compute_u=True)
@@ -163,8 +164,9 @@ def test_vs_oracle(dev, oracle, dn, n):
     ref = oracle.eig_sym(sym)
     truth = np.linalg.eigvalsh(sym.astype(np.float64))
     # reference-order arithmetic: the oracle's values in the oracle's order
-    ev = n_(Q().eig_sym(sd, arithmetic='reference'))
+    ev = n_(Q().eig_sym(sd))                       # default arithmetic, position by position
     assert relerr(ev, ref) <= tol
+    assert np.array_equal(ev, n_(Q().eig_sym(sd, arithmetic='reference')))
     # fast sweeps: the same set within the error model (float64: the truth is numpy.linalg in float64,
     # itself good to a few n * eps, which the model's floor covers)
     evf = n_(Q().eig_sym(sd, arithmetic='fast'))
@@ -207,8 +209,8 @@ def test_layouts_and_errors(dev, oracle):
     sym = (a + a.swapaxes(-1, -2)) / 2
     ref = oracle.eig_sym(sym)
     sd = t(sym, dev)
-    assert relerr(n_(Q().eig_sym(sd, arithmetic='reference')), ref) <= 1e-11
-    assert relerr(np.sort(n_(Q().eig_sym(sd)), -1), np.sort(ref, -1)) <= 1e-11          # default: fast sweeps
+    assert relerr(n_(Q().eig_sym(sd)), ref) <= 1e-11                                     # default: reference order
+    assert relerr(np.sort(n_(Q().eig_sym(sd, arithmetic='fast')), -1), np.sort(ref, -1)) <= 1e-11
     # matrix-first ("channel-first") storage: (3, 3, B, X, Y) viewed as (B, X, Y, 3, 3)
     cf = sd.permute(3, 4, 0, 1, 2).contiguous().permute(2, 3, 4, 0, 1)
     assert not cf.is_contiguous()
@@ -305,8 +307,8 @@ def test_eig_sym_fast_last_stage_closed_form(dev, dn):
     a[5] = torch.tensor([[1.0, 2.0], [2.0, -3.0]], dtype=torch.float64) * big              # delta^2 + b^2 overflows the safe range
     a[6] = torch.tensor([[1.0, 2.0], [2.0, -3.0]], dtype=torch.float64) * small            # ... and underflows it
     ad = a.to(dtype).to(dev)
-    v, u = Q().eig_sym(ad, compute_u=True)
-    v0 = Q().eig_sym(ad)
+    v, u = Q().eig_sym(ad, compute_u=True, arithmetic='fast')
+    v0 = Q().eig_sym(ad, arithmetic='fast')
     assert torch.equal(v, v0)
     a64 = ad.double().cpu()
     truth = torch.linalg.eigvalsh(a64)
@@ -325,11 +327,11 @@ def test_eig_sym_fast_last_stage_closed_form(dev, dn):
     b = torch.randn(1000, 4, 4, generator=g, dtype=torch.float64)
     b = (b + b.transpose(-1, -2)).to(dtype).to(dev)
     tri = Q().hessenberg_sym(b)
-    none = n_(Q().eig_sym(b, max_iter=0))
+    none = n_(Q().eig_sym(b, max_iter=0, arithmetic='fast'))
     # (a reflector is ill-determined where the column below the diagonal is small, so two roundings of
     # the tridiagonalisation agree only loosely entry by entry)
     assert relerr(none, n_(tri.diagonal(0, -1, -2))) <= 1e4 * eps
-    assert relerr(none, n_(Q().eig_sym(b))) > 1e-2
+    assert relerr(none, n_(Q().eig_sym(b, arithmetic='fast'))) > 1e-2
 
 
 @pytest.mark.parametrize('n', [3, 4, 6, 8])
@@ -344,21 +346,73 @@ def test_eig_sym_fast_tolerance_floor(dev, oracle, n):
     truth = np.linalg.eigvalsh(a.astype(np.float64))
     scale = np.abs(truth).max(-1, keepdims=True)
     ref = np.sort(oracle.eig_sym(a), -1)
-    fast = np.sort(n_(Q().eig_sym(t(a, dev))), -1)
+    fast = np.sort(n_(Q().eig_sym(t(a, dev), arithmetic='fast')), -1)
     err_ref = (np.abs(ref - truth) / scale).max()
     err_fast = (np.abs(fast - truth) / scale).max()
     assert err_fast <= 2 * err_ref + 4 * n * EPS['f32'], (err_fast, err_ref)
     # mean error too: the floor must not shift the bulk, not only the worst case
     assert (np.abs(fast - truth) / scale).mean() <= 1.5 * (np.abs(ref - truth) / scale).mean()
     # a loose caller tolerance is kept (errors of its size appear), a tight one is floored
-    loose = np.sort(n_(Q().eig_sym(t(a, dev), tol=1e-4)), -1)
+    loose = np.sort(n_(Q().eig_sym(t(a, dev), tol=1e-4, arithmetic='fast')), -1)
     err_loose = (np.abs(loose - truth) / scale).max()
     assert 4 * err_fast < err_loose < 2e-2
-    tight = n_(Q().eig_sym(t(a, dev), tol=0.0))
+    tight = n_(Q().eig_sym(t(a, dev), tol=0.0, arithmetic='fast'))
     assert np.array_equal(np.sort(tight, -1), fast)
     # float64: the default tolerance is above the floor -> same iterates as before the floor existed
     a64 = a[:2000].astype(np.float64)
-    f64 = n_(Q().eig_sym(t(a64, dev)))
-    assert np.array_equal(f64, n_(Q().eig_sym(t(a64, dev), tol=1e-32)))
+    f64 = n_(Q().eig_sym(t(a64, dev), arithmetic='fast'))
+    assert np.array_equal(f64, n_(Q().eig_sym(t(a64, dev), tol=1e-32, arithmetic='fast')))
     t64 = np.linalg.eigvalsh(a64)
     assert (np.abs(np.sort(f64, -1) - t64) / np.abs(t64).max(-1, keepdims=True)).max() <= 8 * n * EPS['f64']
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 8])
+def test_eig_sym_default_bits_across_ranges(dev, oracle, dn, n):
+    """The default arithmetic runs division / square root as the IEEE sequences WITHOUT their range
+    handling when a wavefront vote finds every operand in range (nfm_qr_core.hpp, CrRange), and the
+    full sequences otherwise: bit-identical to the oracle either way -- matrices scaled across the
+    exponent range (in range, out of range at both ends, and both kinds mixed inside one wavefront),
+    exact zeros (diagonal / block-diagonal / zero matrices), denormal entries, and non-finite input."""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    rng = np.random.default_rng(500 + n)
+    nb = 64 * 40
+    a = rng.standard_normal((nb, n, n))
+    a = a + a.swapaxes(-1, -2)
+    ex = (-30, -20, -14, -8, 0, 5, 8, 12, 18) if dn == 'f32' else (-250, -190, -120, -40, 0, 20, 45, 70, 140)
+    scale = np.ones(nb)
+    for i, e in enumerate(ex):                      # whole wavefronts at one scale ...
+        scale[64 * i:64 * (i + 1)] = 10.0 ** e
+    mixed = slice(64 * len(ex), 64 * (len(ex) + 8))   # ... and wavefronts that mix the scales lane by lane
+    scale[mixed] = 10.0 ** rng.choice(ex, size=64 * 8)
+    a = a * scale[:, None, None]
+    k = 64 * (len(ex) + 8)
+    a[k:k + 16] = np.eye(n) * rng.standard_normal((16, 1, n))           # diagonal
+    a[k + 16:k + 24] = 0.0                                                # zero
+    if n >= 3:                                                            # block diagonal: exact zeros off the blocks
+        a[k + 24:k + 40, 0, 1:] = 0.0
+        a[k + 24:k + 40, 1:, 0] = 0.0
+    tiny = np.finfo(dtype).tiny
+    a[k + 40:k + 48] = rng.standard_normal((8, n, n)) * tiny * 4          # denormal-sized entries
+    a[k + 40:k + 48] += a[k + 40:k + 48].swapaxes(-1, -2).copy()
+    a = a.astype(dtype)
+    ref = oracle.eig_sym(a)
+    got = n_(Q().eig_sym(t(a, dev)))
+    assert np.array_equal(got, ref, equal_nan=True), np.argwhere(~((got == ref) | (np.isnan(got) & np.isnan(ref))))[:8]
+    rv, ru = oracle.eig_sym(a, True)
+    gv, gu = Q().eig_sym(t(a, dev), compute_u=True)
+    assert np.array_equal(n_(gv), rv, equal_nan=True) and np.array_equal(n_(gu), ru, equal_nan=True)
+    # non-finite input (check_finite=False): NaN where the oracle has NaN
+    b = a[:256].copy()
+    b[::7, 0, 0] = np.nan
+    b[3::11, -1, 0] = np.inf
+    b[3::11, 0, -1] = np.inf
+    ref = oracle.eig_sym(b)
+    got = n_(Q().eig_sym(t(b, dev), check_finite=False))
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok], ref[ok])
+    # a caller tolerance above one ulp takes the unscreened "stuck" test: same bits
+    for tol in (1e-4, 1e-10):
+        c = a[:1024]
+        assert np.array_equal(n_(Q().eig_sym(t(c, dev), tol=tol)), oracle.eig_sym(c, tol=tol), equal_nan=True)
