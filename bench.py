@@ -65,6 +65,12 @@ def parse(argv=None):
                         'separately as gather_ms; never part of value)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help='gloo = CPU launcher self-test (--workload null), or a rehearsal with --share-gpu')
+    p.add_argument('--timeout-s', type=float, default=1500.0,
+                   help='self-launched ranks: overall deadline of the job (on expiry the spawned PIDs are terminated, '
+                        'then killed, and the exit code is 124); every rank: deadline of the rendezvous and of each '
+                        'collective (init_process_group timeout)')
+    p.add_argument('--fail-rank', type=int, default=-1,
+                   help='TEST HOOK: this rank exits 1 before the rendezvous (tests/test_bench_launcher.py)')
     p.add_argument('--share-gpu', action='store_true',
                    help='REHEARSAL of the N > 1 path on a one-GPU box: every rank runs the real workload on cuda:0 '
                         '(needs --backend gloo: RCCL refuses two ranks on one device).  The line says so '
@@ -95,10 +101,13 @@ def launch_ranks(a, argv):
                    LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    NFM_BENCH_SELF_LAUNCHED='1')
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # rank 0's stdout is the JSON line; what the other ranks print goes to stderr (kept, not discarded)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=None if r == 0 else sys.stderr))
     rc = 0
     pending = dict(enumerate(procs))
+    deadline = time.monotonic() + a.timeout_s
+    kill_at = None
     while pending:
         for r, p in list(pending.items()):
             code = p.poll()
@@ -110,6 +119,19 @@ def launch_ranks(a, argv):
                 print(f'bench.py: rank {r} exited with {code}; stopping the other ranks', file=sys.stderr)
                 for q in pending.values():      # exactly the PIDs started above
                     q.terminate()
+                kill_at = time.monotonic() + 10.0
+        now = time.monotonic()
+        if pending and now > deadline and kill_at is None:
+            print(f'bench.py: ranks {sorted(pending)} still running after --timeout-s {a.timeout_s:.0f}; '
+                  f'terminating them', file=sys.stderr)
+            rc = rc or 124
+            for q in pending.values():
+                q.terminate()
+            kill_at = now + 10.0
+        if pending and kill_at is not None and now > kill_at:
+            for q in pending.values():          # a rank that ignored SIGTERM (hung in a collective / on the GPU)
+                q.kill()
+            kill_at = now + 3600.0
         time.sleep(0.05)
     return rc
 
@@ -471,6 +493,9 @@ def run_rank(a):
         print('bench.py: --backend gloo only runs the launcher self-test (--workload null) or a --share-gpu '
               'rehearsal; the product has no CPU path', file=sys.stderr)
         return 2
+    if a.fail_rank == rank:
+        print(f'bench.py: rank {rank} fails before the rendezvous (--fail-rank test hook)', file=sys.stderr)
+        return 1
     from nitorch_fastmath_amd.shard import max_over_ranks
     if on_gpu:
         device = torch.device('cuda', 0 if (a.share_gpu or world == 1) else local_rank)
@@ -479,10 +504,13 @@ def run_rank(a):
         device = torch.device('cpu')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import datetime
+        # the deadline covers the rendezvous (a rank that never arrives) and every collective after it
+        tmo = datetime.timedelta(seconds=max(10.0, a.timeout_s))
         if a.backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+            dist.init_process_group('gloo', rank=rank, world_size=world, timeout=tmo)
 
     w = make_workload(a.workload, a.n, device, rank, a.layout)
 
@@ -507,6 +535,16 @@ def run_rank(a):
 
     for _ in range(a.warmup):
         w.step()
+    # what the same K steps cost WITHOUT the settle phase below (the first launches after the idle gap of
+    # input generation run slower: power-state ramp) -- reported next to the headline, never part of `value`
+    cold_ms = None
+    if a.settle_ms > 0 and on_gpu:
+        c0 = event()
+        for _ in range(a.steps):
+            w.step()
+        c1 = event()
+        sync()
+        cold_ms = elapsed_ms(c0, c1) / a.steps
     settle_steps = 0
     if a.settle_ms > 0 and on_gpu:
         sync()
@@ -530,6 +568,20 @@ def run_rank(a):
     kern_ms = elapsed_ms(marks[0], marks[-1]) / a.steps      # average launch duration on the stream
     median_ms, min_ms = per_step[len(per_step) // 2], per_step[0]
     ranks_seen, devices = census(world, device, dist, None if a.backend == 'nccl' else torch.device('cpu'))
+    # every rank checks ITS OWN last timed output against the oracle (outside the timed region) and reports its
+    # own per-step kernel times, so that an N > 1 line carries parity and a slow point can be attributed
+    parity = None
+    if not a.no_cpu and w.check is not None:
+        import oracle as O
+        O.build()
+        O.set_num_threads(max(1, host_cores() // world))
+        parity = w.check()
+    per_rank = [{'rank': rank, 'kernel_ms': kern_ms, 'kernel_ms_median': median_ms, 'kernel_ms_min': min_ms,
+                 'parity': parity}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
     gather_ms = None
     if a.gather and w.output is not None and world > 1:
         from nitorch_fastmath_amd.shard import gather_outputs
@@ -553,6 +605,7 @@ def run_rank(a):
         'scaling': 'weak', 'vs_baseline': None, 'dtype': w.dtype, 'data': 'synthetic',
         'config': {'workload': w.desc, 'per_gpu_units': w.units, 'parallelism': f'batch-shard x{world}',
                    'layout': a.layout, 'kernel': w.kernel, 'settle_steps': settle_steps,
+                   'warmup_effective': a.warmup + (a.steps if cold_ms is not None else 0) + settle_steps,
                    'launcher': 'bench.py (self-launched ranks)' if os.environ.get('NFM_BENCH_SELF_LAUNCHED')
                    else ('external (WORLD_SIZE in env)' if world > 1 else 'single process')},
         'ranks_seen': ranks_seen, 'distinct_devices': distinct, 'devices': devices,
@@ -574,19 +627,27 @@ def run_rank(a):
                             'frac_at_median': w.units * w.bytes_per_unit / (median_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             'frac_at_min': w.units * w.bytes_per_unit / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             'frac_of_achievable_6300': achieved / 6300.0}
+        if cold_ms is not None:
+            # the same K steps timed right after the W warm-ups, before the settle phase
+            line['roofline']['kernel_ms_without_settle'] = cold_ms
+            line['roofline']['frac_without_settle'] = w.units * w.bytes_per_unit / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if world > 1:
+            line['roofline']['per_rank_kernel_ms_median'] = [r['kernel_ms_median'] for r in per_rank]
+            line['roofline']['per_rank_kernel_ms'] = [r['kernel_ms'] for r in per_rank]
     if gather_ms is not None:
         line['gather_ms'] = gather_ms   # optional xGMI all-gather of the outputs, outside `value`
-    if world == 1 and not a.no_cpu and w.check is not None:
-        # the CPU leg (rank 0, one GPU only): the oracle checks the output of the LAST TIMED STEP,
-        # then is timed as the baseline
-        import oracle as O
-        O.build()
-        avail = host_cores()
-        O.set_num_threads(avail)
-        line['parity'] = w.check()
-        if not line['parity']['ok']:
+    checked = [r['parity'] for r in per_rank if r['parity'] is not None]
+    if checked:
+        # the oracle checked the output of the LAST TIMED STEP on every rank: the line carries the worst one
+        worst = max(checked, key=lambda v: (not v['ok'], v['max_rel_err_vs_oracle']))
+        line['parity'] = dict(worst, ranks_checked=len(checked), ranks_ok=sum(1 for v in checked if v['ok']))
+        if not all(v['ok'] for v in checked) or len(checked) != world:
             print('bench.py: PARITY FAILED against the oracle', file=sys.stderr)
             rc = 4
+    if world == 1 and not a.no_cpu and w.check is not None:
+        # the CPU baseline leg (rank 0, one GPU only)
+        import oracle as O
+        avail = host_cores()
         best = None
         # a one-GPU box owns a share of the host (16 threads by the pool's rule); try that
         # and everything visible, keep the faster, report the thread count actually used

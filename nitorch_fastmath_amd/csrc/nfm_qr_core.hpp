@@ -299,7 +299,15 @@ __device__ __forceinline__ void rot_pair1(T &a0, T &a1, T c, T s)
         const V2<float> v = {a0, a1};
         const V2<float> t = v * s, w = v * c;
         V2<float> o;
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(w), "v"(t));
+#ifdef NFM_EXP_NOASM
+        o.x = w.x - t.y; o.y = w.y + t.x;
+#else
+        // (device inline asm is `convergent` by default, which keeps the loops around it from unrolling early
+        // and the matrix from being promoted to registers; this statement touches no other lane)
+        [[clang::noconvergent]] {
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(w), "v"(t));
+        }
+#endif
         a0 = o.x;
         a1 = o.y;
     } else {
@@ -630,28 +638,36 @@ __device__ __forceinline__ T wilkinson_cr1(T h0, T h1, T b)
     return h1 - div_cr(sb2, den, rcp_cr(den));
 }
 
-// rq_step1(..., sym = true) of eig_sym's reference-order sweeps: the same operations on the same
-// entries (the tridiagonal shortcut of _rq_hessenberg_jit_ :457-485), rotations by givens_cr1 / rot_pair1
+// rq_step1(..., sym = true) of eig_sym's reference-order sweeps on BAND storage.  The tridiagonal shortcut
+// of _rq_hessenberg_jit_ :457-485 rotates rows k, k+1 over columns k..k+2 and columns k, k+1 over rows
+// k-1..k+1: only four diagonals of the matrix are ever read or written --
+//   d[i] = a[i][i],  l[i] = a[i+1][i],  u1[i] = a[i][i+1],  u2[i] = a[i][i+2]
+// (l and u1 drift apart by rounding and u2 fills with rounding residue: all three are carried because
+// the reference carries them).  The same operations on the same entries, so the same bits, in 4 n
+// registers instead of n^2; rotations by givens_cr1 / rot_pair1.  Loop bounds are literal (the vote in
+// givens_cr1 is a convergent operation: loops around one only unroll early when their trip count is).
 template <typename T, int NT, bool WITH_U>
-__device__ __forceinline__ void rq_step_cr1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                            int n, int m)
+__device__ __forceinline__ void band_sweep_cr1(T (&d)[Dim<NT>::MAX], T (&l)[Dim<NT>::MAX], T (&u1)[Dim<NT>::MAX],
+                                               T (&u2)[Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m)
 {
     constexpr int MX = Dim<NT>::MAX;
     T lc[MX], ls[MX];
 #pragma unroll
     for (int k = 0; k < MX - 1; ++k) {
         if (k < m - 1) {
-            givens_cr1(a[k][k], a[k + 1][k], lc[k], ls[k]);
-#pragma unroll
-            for (int j = k; j < MX && j < k + 3; ++j)
-                if (j < m) rot_pair1(a[k][j], a[k + 1][j], lc[k], ls[k]);
+            givens_cr1(d[k], l[k], lc[k], ls[k]);
+            rot_pair1(d[k], l[k], lc[k], ls[k]);          // column k:   (a[k][k],   a[k+1][k])
+            rot_pair1(u1[k], d[k + 1], lc[k], ls[k]);     // column k+1: (a[k][k+1], a[k+1][k+1])
+            if (k + 2 < MX)
+                if (k + 2 < m) rot_pair1(u2[k], u1[k + 1], lc[k], ls[k]); // column k+2: (a[k][k+2], a[k+1][k+2])
         }
     }
 #pragma unroll
     for (int k = 0; k < MX - 1; ++k) {
         if (k < m - 1) {
-#pragma unroll
-            for (int i = (k > 0 ? k - 1 : 0); i < k + 2; ++i) rot_pair1(a[i][k], a[i][k + 1], lc[k], ls[k]);
+            if (k >= 1) rot_pair1(u1[k - 1 < 0 ? 0 : k - 1], u2[k - 1 < 0 ? 0 : k - 1], lc[k], ls[k]); // row k-1
+            rot_pair1(d[k], u1[k], lc[k], ls[k]);         // row k:   (a[k][k],   a[k][k+1])
+            rot_pair1(l[k], d[k + 1], lc[k], ls[k]);      // row k+1: (a[k+1][k], a[k+1][k+1])
             if (WITH_U) {
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
@@ -659,6 +675,86 @@ __device__ __forceinline__ void rq_step_cr1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], 
             }
         }
     }
+}
+
+// _qr_explicit(_vectors)_jit_ :572-656 with sym = True in the reference's operation order on band storage
+// (band_sweep_cr1); convergence per lane (Q9).  On return the diagonal of h holds the eigenvalues.
+template <typename T, int NT, bool WITH_U>
+__device__ __forceinline__ void qr_explicit_band1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
+                                                  int n, int max_iter, double tol)
+{
+#pragma clang fp contract(off)
+    constexpr int MX = Dim<NT>::MAX;
+    // the exact "stuck" test can be screened by an estimate when its threshold is below half an ulp of T
+    const bool screen_stuck = tol * 1e-3 < (sizeof(T) == 4 ? 0x1p-25 : 0x1p-54);
+    T d[MX], l[MX], u1[MX], u2[MX];
+#pragma unroll
+    for (int i = 0; i < MX; ++i) {
+        d[i] = h[i][i];
+        l[i] = (i + 1 < MX) ? h[i + 1 < MX ? i + 1 : i][i] : T(0);
+        u1[i] = (i + 1 < MX) ? h[i][i + 1 < MX ? i + 1 : i] : T(0);
+        u2[i] = (i + 2 < MX) ? h[i][i + 2 < MX ? i + 2 : i] : T(0);
+    }
+    if (WITH_U) {
+#pragma unroll
+        for (int i = 0; i < MX; ++i)
+#pragma unroll
+            for (int j = 0; j < MX; ++j) u[i][j] = (i == j) ? T(1) : T(0);
+    }
+#pragma unroll
+    for (int m = MX; m >= 2; --m) {
+        if (m <= n) {
+            double sos_prev = 0.0;
+            T ratio_prev = T(0), low_prev = T(0), diag_prev = T(1);
+            for (int it = 0; it < max_iter; ++it) {
+                const T sigma = wilkinson_cr1(d[m - 2], d[m - 1], l[m - 2]);
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < m) d[i] -= sigma;
+                band_sweep_cr1<T, NT, WITH_U>(d, l, u1, u2, u, n, m);
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < m) d[i] += sigma;
+                const T bb = fabs_(l[m - 2]), a0 = fabs_(d[m - 1]), a1 = fabs_(d[m - 2]);
+                const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
+                // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
+                // more: a zero off-diagonal (diagonal or zero blocks, padding lanes of the last
+                // tile) or NaNs would otherwise spin through all max_iter identical iterations
+                if ((double)sos_lower <= tol * (double)sos_diag || sos_lower != sos_lower) {
+                    l[m - 2] = T(0); // h[m-1][:m-1] = 0: the only entry of that row the band holds
+                    break;
+                }
+                if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
+                    // |prev - new| / prev < tol * 1e-3 with new = sos_lower / sos_diag correctly rounded in T,
+                    // written without the fp64 division (prev > 0).  Below a relative threshold of one ulp of T
+                    // the exit can only fire when the two quotients are EQUAL, so the division itself is only
+                    // run when an estimate (v_rcp: a few ulp) says they may be: a wavefront vote, the
+                    // reference's decision bit for bit either way.
+                    if (screen_stuck) {
+                        const T ratio = sos_lower * hw_rcp(sos_diag);
+                        const bool far = fabs_(ratio - ratio_prev) > ratio_prev * T(0x1p-18); // NaN / inf: not far
+                        const T lp = low_prev, dp = diag_prev;
+                        ratio_prev = ratio;
+                        low_prev = sos_lower;
+                        diag_prev = sos_diag;
+                        if (__builtin_expect(__any(!far), 0)) {
+                            const double snew = (double)(sos_lower / sos_diag);
+                            const double sprev = it > 0 ? (double)(lp / dp) : 0.0;
+                            const double dif = sprev - snew;
+                            if (!far && sprev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sprev) break;
+                        }
+                    } else {
+                        const double sos_new = (double)(sos_lower / sos_diag);
+                        const double dif = sos_prev - sos_new;
+                        if (sos_prev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sos_prev) break;
+                        sos_prev = sos_new;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MX; ++i) h[i][i] = d[i];
 }
 
 // the same shift for the fast sweeps: hardware sqrt / rcp (a shift only steers the iteration)
@@ -776,89 +872,49 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
     constexpr bool FM = FAST && FastSweeps<T>::on;
-    // The reference deflates when e^2 < tol (d0^2 + d1^2) with tol = 1e-32 by default: |e| < 1e-16 |d|,
-    // the working precision of float64 -- but eight orders below float32's, where it costs one more
-    // sweep per eigenvalue just to square an off-diagonal that is already below half an ulp.  The fast
-    // sweeps floor the tolerance at the working precision of the dtype, |e| <= eps/4 |d| (the neglected
-    // entry moves an eigenvalue by at most |e|: a quarter of an ulp); a larger caller tolerance is kept.
-    if constexpr (FM) {
+    if constexpr (!FM) { // the reference's operation order (the default): its own loop on band storage
+        qr_explicit_band1<T, NT, WITH_U>(h, u, n, max_iter, tol);
+    } else {
+        // The reference deflates when e^2 < tol (d0^2 + d1^2) with tol = 1e-32 by default: |e| < 1e-16 |d|,
+        // the working precision of float64 -- but eight orders below float32's, where it costs one more
+        // sweep per eigenvalue just to square an off-diagonal that is already below half an ulp.  The fast
+        // sweeps floor the tolerance at the working precision of the dtype, |e| <= eps/4 |d| (the neglected
+        // entry moves an eigenvalue by at most |e|: a quarter of an ulp); a larger caller tolerance is kept.
         const double floor_ = sizeof(T) == 4 ? 0x1p-52 : 0x1p-110; // (eps / 4)^2, eps = 2^-24 / 2^-53
         tol = tol > floor_ ? tol : floor_;
-    }
-    const T tol_t = (T)tol, stuck_t = (T)(tol * 1e-3);
-    // the exact "stuck" test can be screened by an estimate when its threshold is below half an ulp of T
-    const bool screen_stuck = tol * 1e-3 < (sizeof(T) == 4 ? 0x1p-25 : 0x1p-54);
-    if (WITH_U) {
+        const T tol_t = (T)tol, stuck_t = (T)(tol * 1e-3);
+        if (WITH_U) {
 #pragma unroll
-        for (int i = 0; i < MX; ++i)
+            for (int i = 0; i < MX; ++i)
 #pragma unroll
-            for (int j = 0; j < MX; ++j) u[i][j] = (i == j) ? T(1) : T(0);
-    }
+                for (int j = 0; j < MX; ++j) u[i][j] = (i == j) ? T(1) : T(0);
+        }
 #pragma unroll
-    for (int m = MX; m >= 2; --m) {
-        if (m <= n) {
-            int iters = max_iter;
-            if constexpr (FM) {
+        for (int m = MX; m >= 2; --m) {
+            if (m <= n) {
+                int iters = max_iter;
                 if (m == 2 && max_iter > 0)
                     if (jacobi2_fast1<T, NT, WITH_U>(h, u, n)) iters = 0;
-            }
-            double sos_prev = 0.0;
-            T ratio_prev = T(0), low_prev = T(0), diag_prev = T(1);
-            for (int it = 0; it < iters; ++it) {
-                T sigma;
-                if constexpr (FM) sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
-                else sigma = wilkinson_cr1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
-                if constexpr (FM) {
+                T ratio_prev = T(0);
+                for (int it = 0; it < iters; ++it) {
+                    const T sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
                     tri_sweep_fast1<T, NT, WITH_U>(h, u, n, m, sigma);
-                } else {
+                    const T bb = fabs_(h[m - 1][m - 2]), a0 = fabs_(h[m - 1][m - 1]), a1 = fabs_(h[m - 2][m - 2]);
+                    const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
+                    // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
+                    // more: a zero off-diagonal (diagonal or zero blocks, padding lanes of the last
+                    // tile) or NaNs would otherwise spin through all max_iter identical iterations
+                    const bool conv = sos_lower <= tol_t * sos_diag; // in T: tol_t >= (eps/4)^2 is a normal number
+                    if (conv || sos_lower != sos_lower) {
 #pragma unroll
-                    for (int i = 0; i < m; ++i) h[i][i] -= sigma;
-                    rq_step_cr1<T, NT, WITH_U>(h, u, n, m);
-#pragma unroll
-                    for (int i = 0; i < m; ++i) h[i][i] += sigma;
-                }
-                const T bb = fabs_(h[m - 1][m - 2]), a0 = fabs_(h[m - 1][m - 1]), a1 = fabs_(h[m - 2][m - 2]);
-                const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
-                // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
-                // more: a zero off-diagonal (diagonal or zero blocks, padding lanes of the last
-                // tile) or NaNs would otherwise spin through all max_iter identical iterations
-                bool conv;
-                if constexpr (FM) conv = sos_lower <= tol_t * sos_diag; // in T: tol_t >= (eps/4)^2 is a normal number
-                else conv = (double)sos_lower <= tol * (double)sos_diag;
-                if (conv || sos_lower != sos_lower) {
-#pragma unroll
-                    for (int j = 0; j < m - 1; ++j) h[m - 1][j] = T(0);
-                    break;
-                }
-                if constexpr (FM && !WITH_U) { // the same exit in T (the ratio only detects a fixed point)
-                    const T ratio = sos_lower * hw_rcp(sos_diag);
-                    const T dif = fabs_(ratio_prev - ratio);
-                    if (ratio_prev != T(0) && dif < stuck_t * ratio_prev) break;
-                    ratio_prev = ratio;
-                } else if (!WITH_U) { // the "stuck" exit exists only in the no-vectors variant :648-653
-                    // |prev - new| / prev < tol * 1e-3 with new = sos_lower / sos_diag correctly rounded in T,
-                    // written without the fp64 division (prev > 0).  Below a relative threshold of one ulp of T
-                    // the exit can only fire when the two quotients are EQUAL, so the division itself is only
-                    // run when an estimate (v_rcp: a few ulp) says they may be: a wavefront vote, the
-                    // reference's decision bit for bit either way.
-                    if (screen_stuck) {
+                        for (int j = 0; j < m - 1; ++j) h[m - 1][j] = T(0);
+                        break;
+                    }
+                    if constexpr (!WITH_U) { // the "stuck" exit :648-653 in T (the ratio only detects a fixed point)
                         const T ratio = sos_lower * hw_rcp(sos_diag);
-                        const bool far = fabs_(ratio - ratio_prev) > ratio_prev * T(0x1p-18); // NaN / inf: not far
-                        const T lp = low_prev, dp = diag_prev;
+                        const T dif = fabs_(ratio_prev - ratio);
+                        if (ratio_prev != T(0) && dif < stuck_t * ratio_prev) break;
                         ratio_prev = ratio;
-                        low_prev = sos_lower;
-                        diag_prev = sos_diag;
-                        if (__builtin_expect(__any(!far), 0)) {
-                            const double snew = (double)(sos_lower / sos_diag);
-                            const double sprev = it > 0 ? (double)(lp / dp) : 0.0;
-                            const double dif = sprev - snew;
-                            if (!far && sprev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sprev) break;
-                        }
-                    } else {
-                        const double sos_new = (double)(sos_lower / sos_diag);
-                        const double dif = sos_prev - sos_new;
-                        if (sos_prev != 0.0 && (dif < 0 ? -dif : dif) < (tol * 1e-3) * sos_prev) break;
-                        sos_prev = sos_new;
                     }
                 }
             }

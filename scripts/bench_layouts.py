@@ -9,12 +9,11 @@ import nitorch_fastmath_amd as N  # noqa: E402
 dev = torch.device('cuda:0')
 
 
+from _timing import timeit as _timeit
+
 def timeit(fn, reps=8):
-    fn(); fn(); torch.cuda.synchronize(); best = 1e9
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); e1.synchronize(); best = min(best, e0.elapsed_time(e1) * 1e-3)
-    return best
+    return _timeit(fn, reps)           # seconds, steady state (scripts/_timing.py)
+
 
 
 print('| layout | M | n | ms | solves/s | algorithmic GB/s |')

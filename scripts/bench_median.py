@@ -11,12 +11,11 @@ dev = torch.device('cuda:0')
 with_torch = '--no-torch' not in sys.argv
 
 
+from _timing import timeit as _timeit
+
 def timeit(fn, reps=5):
-    fn(); torch.cuda.synchronize(); best = 1e9
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); e1.synchronize(); best = min(best, e0.elapsed_time(e1) * 1e-3)
-    return best
+    return _timeit(fn, reps)           # seconds, steady state (scripts/_timing.py)
+
 
 
 print('# median: radix selection (nfm_reduce_median) vs torch.median on the same MI355X, contiguous (rows, red)\n')

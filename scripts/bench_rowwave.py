@@ -18,19 +18,11 @@ def arm():
     import nitorch_fastmath_amd as N
     dev = torch.device('cuda:0')
 
+    from _timing import timeit as _timeit
+
     def timeit(fn, reps=6):
-        fn()
-        fn()
-        torch.cuda.synchronize()
-        best = 1e9
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            e1.synchronize()
-            best = min(best, e0.elapsed_time(e1))
-        return best
+        return _timeit(fn, reps) * 1e3     # ms, steady state (scripts/_timing.py)
+
 
     for dtype, dn, sz in ((torch.float32, 'f32', 4), (torch.float64, 'f64', 8)):
         for M in range(9, 17):

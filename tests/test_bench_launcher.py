@@ -76,6 +76,46 @@ def test_failing_rank_fails_the_job():
     assert r.returncode != 0 and '{' not in r.stdout
 
 
+def test_self_launch_eight_ranks():
+    """the driver's largest point (N = 8), on gloo with the null workload: rendezvous, census, per-rank lists"""
+    r = run(['--gpus', '8', '--steps', '2', '--warmup', '0', '--workload', 'null', '--backend', 'gloo'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = the_line(r.stdout)
+    assert d['n_gpus'] == 8 and d['ranks_seen'] == 8 and sorted(x['rank'] for x in d['devices']) == list(range(8))
+
+
+def test_rank_dying_before_the_rendezvous_fails_the_job_quickly():
+    """a rank that exits before init_process_group: the launcher stops the ranks waiting at the store and
+    returns non-zero well inside the deadline; no line is printed"""
+    import time
+    t0 = time.time()
+    r = run(['--gpus', '3', '--steps', '1', '--warmup', '0', '--workload', 'null', '--backend', 'gloo',
+             '--fail-rank', '1', '--timeout-s', '120'])
+    assert r.returncode != 0 and '{' not in r.stdout and 'rank 1' in r.stderr
+    assert time.time() - t0 < 90
+
+
+def test_hung_job_is_stopped_at_the_deadline():
+    """ranks that never finish (here: waiting for a rank that is not part of the job, WORLD_SIZE says 3,
+    two are started) are terminated at --timeout-s and the exit code says so"""
+    import time
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    t0 = time.time()
+    procs = []
+    for rank in range(2):
+        env = clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='3', MASTER_ADDR='127.0.0.1',
+                        MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, BENCH, '--gpus', '3', '--steps', '1', '--warmup', '0',
+                                       '--workload', 'null', '--backend', 'gloo', '--timeout-s', '15'], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=200) for p in procs]
+    assert all(p.returncode != 0 for p in procs), outs          # the rendezvous deadline, not a hang
+    assert time.time() - t0 < 150
+
+
 def test_launcher_parent_never_imports_torch():
     code = ('import sys; sys.argv=["bench.py"]; sys.path.insert(0, %r); import bench; '
             'a = bench.parse(["--gpus", "2"]); assert "torch" not in sys.modules; print("ok")' % ROOT)
