@@ -1,15 +1,19 @@
 // nfm_qr.hip -- Givens / Householder / Hessenberg / QR-algorithm entry points
-// (reference `qr.py`, `_impl/qr.py`).  Orders 1..8 run in registers through rec_kernel;
-// orders 9..16 run the same source with run-time loops (per-lane scratch arrays).
+// (reference `qr.py`, `_impl/qr.py`).  Orders 1..8 run in registers through rec_kernel (orders 9..16 too
+// where the matrices fit a lane's 512 registers: nfm_qr_large.hip); the other orders 9..16 run the same
+// source on matrices held in LDS (qr_lds_kernel below: [element][lane] images, no scratch memory).
 // Multi-output routines write ONE packed output record per matrix (the facade hands out
 // views): eig_sym [vals | vecs], hessenberg [H | reflectors], qr_hessenberg [Q | R], ...
 #include "nfm_record_kernel.hpp"
 #include "nfm_qr_core.hpp"
 
-// This file is compiled four times (-DNFM_QR_PART=0..3), one object per group of entry
-// points, so that the heavy template instantiations build in parallel.
+// This file is compiled twelve times (-DNFM_QR_PART=0..11) so that the heavy template instantiations
+// build in parallel: parts 0..3 hold the entry points and the register kernels of orders 1..8 (one object
+// per group of entry points), parts 4..11 the LDS-resident kernels of orders 9..16 (qr_lds_kernel), one
+// object per (dtype, group of operations): 4 + 4 * f64 + g, g = 0: eig_sym values, 1: eig_sym vectors,
+// 2: hessenberg / qr_hessenberg / householder, 3: hessenberg_sym / rq_hessenberg.
 #ifndef NFM_QR_PART
-#error "compile with -DNFM_QR_PART=0..3"
+#error "compile with -DNFM_QR_PART=0..11"
 #endif
 
 namespace nfm {
@@ -56,11 +60,11 @@ struct EigSymOp {
     static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
                                                  T (&o)[RO::Cs], const Params &p)
     {
-        T a[N][N], u[N][N];
+        T a[N][N], u[N][N], up[N][N], vals[N];
         to_mat<T, N>(r, a, p.upper);
-        qr::eig_sym1<T, N, WITH_U, FAST>(a, u, N, p.max_iter, p.tol);
+        qr::eig_sym1<T, N, WITH_U, FAST>(a, u, up, vals, N, p.max_iter, p.tol);
 #pragma unroll
-        for (int i = 0; i < N; ++i) o[i] = a[i][i];
+        for (int i = 0; i < N; ++i) o[i] = vals[i];
         if constexpr (WITH_U) {
 #pragma unroll
             for (int i = 0; i < N; ++i)
@@ -200,23 +204,44 @@ struct GivensOp {
 enum { QG_EIG = 0, QG_EIG_U, QG_HESS, QG_HESS_U, QG_HESSSYM, QG_HESSSYM_U, QG_QR, QG_RQ, QG_RQ_U, QG_HH,
        QG_EIG_FAST, QG_EIG_U_FAST };
 
-template <typename T, int OP>
-__global__ __launch_bounds__(64) void qr_generic_kernel(Opnd a, Opnd b, T *__restrict__ out, int64_t out_rec,
-                                                        int64_t n_inner, QrParams p)
+// matrices a lane keeps in LDS for OP (n x n elements each)
+constexpr int qg_mats(int op)
+{
+    return op == QG_HH ? 0
+           : (op == QG_EIG_U || op == QG_EIG_U_FAST || op == QG_HESS_U || op == QG_QR || op == QG_RQ_U) ? 2
+                                                                                                      : 1;
+}
+
+// Orders 9..16 whose matrices do not fit the registers of a lane: one matrix per lane all the same, the
+// matrices in LDS as [element][lane] images (qr::LdsMat: conflict-free for any element, literal offsets after
+// unrolling), vectors and the band of the QR sweeps in registers.  LANES lanes per workgroup -- 64, or 32 /
+// 16 when n^2 * matrices * LANES elements would not fit the 160 KiB of a CU (the launcher picks).  The
+// reflectors of the symmetric tridiagonalisation live in the upper triangle of the matrix they came from
+// (UpperRows), so eig_sym with vectors needs two images and hessenberg_sym with reflectors one.
+template <typename T, int OP, int LANES>
+__global__ __launch_bounds__(LANES) void qr_lds_kernel(Opnd a, Opnd b, T *__restrict__ out, int64_t out_rec,
+                                                       int64_t n_inner, QrParams p)
 {
     constexpr int MX = NFM_MAX_DIM;
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char qr_smem[];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * LANES + lane;
     const int64_t o = blockIdx.y;
-    if (i >= n_inner) return;
+    if (i >= n_inner) return; // a lane only touches its own column of the images: no barrier is needed anywhere
     const int n = p.n;
     const T *pa = reinterpret_cast<const T *>(a.ptr) + o * a.so + i * a.si;
     T *po = out + (o * n_inner + i) * out_rec;
-    T m[MX][MX], u[MX][MX];
+    using M = qr::LdsMat<T, LANES>;
+    T *img = reinterpret_cast<T *>(qr_smem);
+    M m{img + lane, n}, u{img + n * n * LANES + lane, n};
     if constexpr (OP == QG_HH) {
         T x[MX];
-        for (int r = 0; r < n; ++r) x[r] = pa[r * a.sc];
+#pragma unroll
+        for (int r = 0; r < MX; ++r) x[r] = (r < n) ? pa[r * a.sc] : T(0);
         const T alpha = qr::householder1<T, 0>(x, n, p.basis);
-        for (int r = 0; r < n; ++r) po[r] = x[r];
+#pragma unroll
+        for (int r = 0; r < MX; ++r)
+            if (r < n) po[r] = x[r];
         po[n] = alpha;
         return;
     } else {
@@ -230,20 +255,32 @@ __global__ __launch_bounds__(64) void qr_generic_kernel(Opnd a, Opnd b, T *__res
             m[r][c] = pa[rr * a.sr + cc * a.sc];
         }
     if constexpr (EIG) {
-        qr::eig_sym1<T, 0, EIGU, OP == QG_EIG_FAST || OP == QG_EIG_U_FAST>(m, u, n, p.max_iter, p.tol);
-        for (int r = 0; r < n; ++r) po[r] = m[r][r];
+        qr::UpperRows<T, M> up{m};
+        T vals[MX];
+        qr::eig_sym1<T, 0, EIGU, OP == QG_EIG_FAST || OP == QG_EIG_U_FAST>(m, u, up, vals, n, p.max_iter, p.tol);
+#pragma unroll
+        for (int r = 0; r < MX; ++r)
+            if (r < n) po[r] = vals[r];
         if (EIGU)
             for (int r = 0; r < n; ++r)
                 for (int c = 0; c < n; ++c) po[n + r * n + c] = u[r][c];
-    } else if constexpr (OP == QG_HESS || OP == QG_HESS_U || OP == QG_HESSSYM || OP == QG_HESSSYM_U) {
-        constexpr bool WU = OP == QG_HESS_U || OP == QG_HESSSYM_U;
-        if constexpr (OP == QG_HESS || OP == QG_HESS_U) qr::hessenberg1<T, 0, WU>(m, n, u);
-        else qr::hessenberg_sym1<T, 0, WU>(m, n, u);
+    } else if constexpr (OP == QG_HESS || OP == QG_HESS_U) {
+        qr::hessenberg1<T, 0, OP == QG_HESS_U>(m, n, u);
         for (int r = 0; r < n; ++r)
             for (int c = 0; c < n; ++c) po[r * n + c] = m[r][c];
-        if (WU)
+        if (OP == QG_HESS_U)
             for (int k = 0; k < n - 2; ++k)
                 for (int c = 0; c < n - 1; ++c) po[n * n + k * (n - 1) + c] = (c < n - 1 - k) ? u[k][c] : T(0);
+    } else if constexpr (OP == QG_HESSSYM || OP == QG_HESSSYM_U) {
+        // the tridiagonal result is written out symmetric from its lower half; the upper half of the image
+        // holds the reflectors (FILL = false)
+        qr::UpperRows<T, M> up{m};
+        qr::hessenberg_sym1<T, 0, OP == QG_HESSSYM_U, false, false, false>(m, n, up);
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) po[r * n + c] = r >= c ? m[r][c] : m[c][r];
+        if (OP == QG_HESSSYM_U)
+            for (int k = 0; k < n - 2; ++k)
+                for (int c = 0; c < n - 1; ++c) po[n * n + k * (n - 1) + c] = (c < n - 1 - k) ? up[k][c] : T(0);
     } else if constexpr (OP == QG_QR) {
         qr::qr_hessenberg1<T, 0>(m, u, n);
         for (int r = 0; r < n; ++r)
@@ -339,17 +376,115 @@ __global__ __launch_bounds__(256) void householder_apply_kernel(Opnd a, Opnd u, 
         break;                       \
     }
 
+template <typename T, int OP, int LANES>
+static int qr_lds_launch_l(const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no, int64_t ni,
+                           const QrParams &p, size_t lds, void *stream)
+{
+    static std::atomic<uint64_t> have{0};
+    if (lds > 64 * 1024) {
+        const int rc = lds_opt_in(have, reinterpret_cast<const void *>(&qr_lds_kernel<T, OP, LANES>), 160 * 1024);
+        if (rc) return rc;
+    }
+    nfm_operand none = {nullptr, 0, 0, 0, 0};
+    const int64_t nblk = (ni + LANES - 1) / LANES;
+    if (nblk > 0x7fffffffLL || no > 65535) return NFM_ESIZE;
+    dim3 grid((unsigned)nblk, (unsigned)no, 1);
+    hipLaunchKernelGGL((qr_lds_kernel<T, OP, LANES>), grid, dim3(LANES), lds, static_cast<hipStream_t>(stream),
+                       make_opnd(a, 0), make_opnd(b ? b : &none, 0), static_cast<T *>(out), out_rec, ni, p);
+    return launch_status();
+}
+
+// 64 lanes per workgroup when their images fit the CU's LDS (at least two workgroups per CU while that is
+// possible), else 32, else 16 (two 16 x 16 float64 images of 64 lanes would be 256 KiB)
+template <typename T, int OP>
+static int qr_lds_launch(const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no,
+                         int64_t ni, const QrParams &p, void *stream)
+{
+    if (no == 0 || ni == 0) return NFM_OK;
+    const size_t per_lane = (size_t)qg_mats(OP) * p.n * p.n * sizeof(T);
+    constexpr size_t cap = 156 * 1024;
+    if (per_lane * 64 <= cap) return qr_lds_launch_l<T, OP, 64>(a, b, out, out_rec, no, ni, p, per_lane * 64, stream);
+    if (per_lane * 32 <= cap) return qr_lds_launch_l<T, OP, 32>(a, b, out, out_rec, no, ni, p, per_lane * 32, stream);
+    return qr_lds_launch_l<T, OP, 16>(a, b, out, out_rec, no, ni, p, per_lane * 16, stream);
+}
+
+// the LDS kernels live in parts 4..11 (one object per dtype and group of operations)
+constexpr int qg_group(int op)
+{
+    return (op == QG_EIG || op == QG_EIG_FAST) ? 0
+           : (op == QG_EIG_U || op == QG_EIG_U_FAST) ? 1
+           : (op == QG_HESS || op == QG_HESS_U || op == QG_QR || op == QG_HH) ? 2
+                                                                             : 3;
+}
+#define NFM_QR_LDS_DECL(t, g)                                                                                          \
+    int qr_lds_##t##_g##g(int op, const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no, \
+                          int64_t ni, const QrParams &p, void *stream);
+NFM_QR_LDS_DECL(f32, 0) NFM_QR_LDS_DECL(f32, 1) NFM_QR_LDS_DECL(f32, 2) NFM_QR_LDS_DECL(f32, 3)
+NFM_QR_LDS_DECL(f64, 0) NFM_QR_LDS_DECL(f64, 1) NFM_QR_LDS_DECL(f64, 2) NFM_QR_LDS_DECL(f64, 3)
+#undef NFM_QR_LDS_DECL
+
 template <typename T, int OP>
 static int qr_generic_launch(const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no,
                              int64_t ni, const QrParams &p, void *stream)
 {
-    if (no == 0 || ni == 0) return NFM_OK;
-    nfm_operand none = {nullptr, 0, 0, 0, 0};
-    dim3 grid((unsigned)((ni + 63) / 64), (unsigned)no, 1);
-    hipLaunchKernelGGL((qr_generic_kernel<T, OP>), grid, dim3(64), 0, static_cast<hipStream_t>(stream),
-                       make_opnd(a, 0), make_opnd(b ? b : &none, 0), static_cast<T *>(out), out_rec, ni, p);
-    return launch_status();
+    constexpr int g = qg_group(OP);
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (g == 0) return qr_lds_f32_g0(OP, a, b, out, out_rec, no, ni, p, stream);
+        else if constexpr (g == 1) return qr_lds_f32_g1(OP, a, b, out, out_rec, no, ni, p, stream);
+        else if constexpr (g == 2) return qr_lds_f32_g2(OP, a, b, out, out_rec, no, ni, p, stream);
+        else return qr_lds_f32_g3(OP, a, b, out, out_rec, no, ni, p, stream);
+    } else {
+        if constexpr (g == 0) return qr_lds_f64_g0(OP, a, b, out, out_rec, no, ni, p, stream);
+        else if constexpr (g == 1) return qr_lds_f64_g1(OP, a, b, out, out_rec, no, ni, p, stream);
+        else if constexpr (g == 2) return qr_lds_f64_g2(OP, a, b, out, out_rec, no, ni, p, stream);
+        else return qr_lds_f64_g3(OP, a, b, out, out_rec, no, ni, p, stream);
+    }
 }
+
+#if NFM_QR_PART >= 4 && NFM_QR_PART <= 11
+#define NFM_QR_LDS_F64 ((NFM_QR_PART - 4) / 4)
+#define NFM_QR_LDS_G ((NFM_QR_PART - 4) % 4)
+#if NFM_QR_LDS_F64
+using TLds = double;
+#define NFM_QR_LDS_NAME(g) qr_lds_f64_g##g
+#else
+using TLds = float;
+#define NFM_QR_LDS_NAME(g) qr_lds_f32_g##g
+#endif
+#define NFM_QR_LDS_CASE(OPv) \
+    case OPv: return qr_lds_launch<TLds, OPv>(a, b, out, out_rec, no, ni, p, stream);
+#if NFM_QR_LDS_G == 0
+int NFM_QR_LDS_NAME(0)(int op, const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no, int64_t ni,
+                       const QrParams &p, void *stream)
+{
+    switch (op) { NFM_QR_LDS_CASE(QG_EIG) NFM_QR_LDS_CASE(QG_EIG_FAST) default: return NFM_EINVAL; }
+}
+#elif NFM_QR_LDS_G == 1
+int NFM_QR_LDS_NAME(1)(int op, const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no, int64_t ni,
+                       const QrParams &p, void *stream)
+{
+    switch (op) { NFM_QR_LDS_CASE(QG_EIG_U) NFM_QR_LDS_CASE(QG_EIG_U_FAST) default: return NFM_EINVAL; }
+}
+#elif NFM_QR_LDS_G == 2
+int NFM_QR_LDS_NAME(2)(int op, const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no, int64_t ni,
+                       const QrParams &p, void *stream)
+{
+    switch (op) {
+        NFM_QR_LDS_CASE(QG_HESS) NFM_QR_LDS_CASE(QG_HESS_U) NFM_QR_LDS_CASE(QG_QR) NFM_QR_LDS_CASE(QG_HH)
+    default: return NFM_EINVAL;
+    }
+}
+#else
+int NFM_QR_LDS_NAME(3)(int op, const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no, int64_t ni,
+                       const QrParams &p, void *stream)
+{
+    switch (op) {
+        NFM_QR_LDS_CASE(QG_HESSSYM) NFM_QR_LDS_CASE(QG_HESSSYM_U) NFM_QR_LDS_CASE(QG_RQ) NFM_QR_LDS_CASE(QG_RQ_U)
+    default: return NFM_EINVAL;
+    }
+}
+#endif
+#endif
 
 // the packed output record is a plain contiguous (n_outer * n_inner, rec) buffer
 static nfm_operand packed_out(void *out, int64_t rec, int64_t ni)
@@ -417,7 +552,17 @@ static int rq_hess_t(int N, int64_t no, int64_t ni, const nfm_operand *a, const 
     const int64_t rec = N * N * (u ? 2 : 1);
     nfm_operand o = packed_out(out, rec, ni);
     if (u) {
-        NFM_QR_SWITCH8(N, return (rec_launch<T, RqHessOp<T, N, true>>(a, u, nullptr, &o, no, ni, p, stream)))
+        // 8 x 8 float64 with U: two 128-register matrices plus the packed output.  Its mixed-layout kernel form
+        // (per-operand mode branches) does not fit the register file, so only the contiguous form is built and
+        // other layouts take the LDS-resident kernel, which reads any strides.
+        NFM_QR_SWITCH8(N, {
+            if constexpr (N == 8 && sizeof(T) == 8) {
+                const int rc = rec_launch<T, RqHessOp<T, N, true>, true>(a, u, nullptr, &o, no, ni, p, stream);
+                if (rc != NFM_EFALLBACK) return rc;
+            } else {
+                return (rec_launch<T, RqHessOp<T, N, true>>(a, u, nullptr, &o, no, ni, p, stream));
+            }
+        })
         return qr_generic_launch<T, QG_RQ_U>(a, u, out, rec, no, ni, p, stream);
     }
     NFM_QR_SWITCH8(N, return (rec_launch<T, RqHessOp<T, N, false>>(a, nullptr, nullptr, &o, no, ni, p, stream)))

@@ -27,6 +27,36 @@ struct Dim {
     static constexpr int MAX = NT > 0 ? NT : NFM_MAX_DIM;
 };
 
+// MATRIX STORAGE.  The routines below only ever write `a[i][j]`: the matrix arguments are template
+// parameters (`MA`, `MU`, ...), bound either to a register array T[MAX][MAX] (compile-time orders: every
+// index is a literal after unrolling) or to an LDS image of the lane's matrix (`LdsMat`: run-time orders
+// 9..16 whose matrices do not fit the lane's registers -- element (i, j) of lane t lives at
+// image[(i * ld + j) * LANES + t], consecutive lanes in consecutive banks, so every access of a wavefront is
+// conflict-free whatever (i, j) is).  Vectors (reflectors, rotation lists, the band of the QR sweeps) are
+// always register arrays indexed by literals.
+template <typename T, int LANES>
+struct LdsMat {
+    T *p;   // &image[lane]
+    int ld; // row stride in elements
+    struct Row {
+        T *p;
+        __device__ __forceinline__ T &operator[](int j) const { return p[j * LANES]; }
+    };
+    __device__ __forceinline__ Row operator[](int i) const { return Row{p + i * ld * LANES}; }
+};
+// reflector k of a symmetric tridiagonalisation stored in row k of the matrix, right of the diagonal
+// (n - 1 - k slots for its n - 1 - k values: the sweeps of eig_sym never read the upper triangle)
+template <typename T, class M>
+struct UpperRows {
+    M m;
+    struct Row {
+        M m;
+        int k;
+        __device__ __forceinline__ T &operator[](int r) const { return m[k][k + 1 + r]; }
+    };
+    __device__ __forceinline__ Row operator[](int k) const { return Row{m, k}; }
+};
+
 __device__ __forceinline__ float sqrt_(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ double sqrt_(double x) { return __builtin_sqrt(x); }
 template <typename T>
@@ -407,9 +437,8 @@ __device__ __forceinline__ T householder1(T (&x)[Dim<NT>::MAX], int m, int basis
 }
 
 // hessenberg_ :117-141.  up[k][r]: reflector k (length n-1-k), kept when WITH_U.
-template <typename T, int NT, bool WITH_U>
-__device__ __forceinline__ void hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n,
-                                            T (&up)[Dim<NT>::MAX][Dim<NT>::MAX])
+template <typename T, int NT, bool WITH_U, class MA, class MU>
+__device__ __forceinline__ void hessenberg1(MA &a, int n, MU &up)
 {
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
@@ -460,9 +489,10 @@ __device__ __forceinline__ void hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], 
 // hessenberg_sym_lower_ :296-323 on a matrix whose LOWER triangle holds the data (the
 // caller mirrors the requested triangle on load, which is what the reference's transposed
 // view does for upper=True).  Output: symmetric tridiagonal, both halves filled.
-template <typename T, int NT, bool WITH_U, bool FAST = false, bool TRIM = false>
-__device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n,
-                                                T (&up)[Dim<NT>::MAX][Dim<NT>::MAX])
+// FILL = false (eig_sym): the upper triangle is left alone (the sweeps run on the band d, e taken from the
+// lower half, and the LDS form keeps the reflectors there)
+template <typename T, int NT, bool WITH_U, bool FAST = false, bool TRIM = false, bool FILL = true, class MA, class MU>
+__device__ __forceinline__ void hessenberg_sym1(MA &a, int n, MU &up)
 {
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
@@ -538,17 +568,18 @@ __device__ __forceinline__ void hessenberg_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MA
                 if (r < n) a[r][k] = T(0);
         }
     }
+    if constexpr (FILL) {
 #pragma unroll
-    for (int i = 0; i < MX; ++i)
+        for (int i = 0; i < MX; ++i)
 #pragma unroll
-        for (int j = 0; j < i; ++j)
-            if (i < n) a[j][i] = a[i][j];
+            for (int j = 0; j < i; ++j)
+                if (i < n) a[j][i] = a[i][j];
+    }
 }
 
 // qr_hessenberg_ :432-454
-template <typename T, int NT>
-__device__ __forceinline__ void qr_hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                               T (&q)[Dim<NT>::MAX][Dim<NT>::MAX], int n)
+template <typename T, int NT, class MA, class MQ>
+__device__ __forceinline__ void qr_hessenberg1(MA &a, MQ &q, int n)
 {
     constexpr int MX = Dim<NT>::MAX;
 #pragma unroll
@@ -572,9 +603,8 @@ __device__ __forceinline__ void qr_hessenberg1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX
 // One R Q step on the leading m x m block; WITH_U also rotates the columns of u (n rows).
 // sym: the tridiagonal shortcut of _rq_hessenberg_jit_ :457-485; otherwise the full ranges.
 // FM: float32 sweep arithmetic (FastSweeps above); only eig_sym's sweeps ask for it.
-template <typename T, int NT, bool WITH_U, bool FM = false>
-__device__ __forceinline__ void rq_step1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                         T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m, bool sym)
+template <typename T, int NT, bool WITH_U, bool FM = false, class MA, class MU>
+__device__ __forceinline__ void rq_step1(MA &a, MU &u, int n, int m, bool sym)
 {
     constexpr int MX = Dim<NT>::MAX;
     T lc[MX], ls[MX];
@@ -646,9 +676,9 @@ __device__ __forceinline__ T wilkinson_cr1(T h0, T h1, T b)
 // the reference carries them).  The same operations on the same entries, so the same bits, in 4 n
 // registers instead of n^2; rotations by givens_cr1 / rot_pair1.  Loop bounds are literal (the vote in
 // givens_cr1 is a convergent operation: loops around one only unroll early when their trip count is).
-template <typename T, int NT, bool WITH_U>
+template <typename T, int NT, bool WITH_U, class MU>
 __device__ __forceinline__ void band_sweep_cr1(T (&d)[Dim<NT>::MAX], T (&l)[Dim<NT>::MAX], T (&u1)[Dim<NT>::MAX],
-                                               T (&u2)[Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m)
+                                               T (&u2)[Dim<NT>::MAX], MU &u, int n, int m)
 {
     constexpr int MX = Dim<NT>::MAX;
     T lc[MX], ls[MX];
@@ -678,28 +708,29 @@ __device__ __forceinline__ void band_sweep_cr1(T (&d)[Dim<NT>::MAX], T (&l)[Dim<
 }
 
 // _qr_explicit(_vectors)_jit_ :572-656 with sym = True in the reference's operation order on band storage
-// (band_sweep_cr1); convergence per lane (Q9).  On return the diagonal of h holds the eigenvalues.
-template <typename T, int NT, bool WITH_U>
-__device__ __forceinline__ void qr_explicit_band1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                                  int n, int max_iter, double tol)
+// (band_sweep_cr1); convergence per lane (Q9).  d, e: the diagonal and the sub-diagonal of the symmetric
+// tridiagonal matrix (the reference's upper sub-diagonal starts as a copy of e, its second one as zeros);
+// on return d holds the eigenvalues.
+template <typename T, int NT, bool WITH_U, class MU>
+__device__ __forceinline__ void qr_explicit_band1(T (&d)[Dim<NT>::MAX], T (&l)[Dim<NT>::MAX], MU &u, int n, int max_iter,
+                                                  double tol)
 {
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
     // the exact "stuck" test can be screened by an estimate when its threshold is below half an ulp of T
     const bool screen_stuck = tol * 1e-3 < (sizeof(T) == 4 ? 0x1p-25 : 0x1p-54);
-    T d[MX], l[MX], u1[MX], u2[MX];
+    T u1[MX], u2[MX];
 #pragma unroll
     for (int i = 0; i < MX; ++i) {
-        d[i] = h[i][i];
-        l[i] = (i + 1 < MX) ? h[i + 1 < MX ? i + 1 : i][i] : T(0);
-        u1[i] = (i + 1 < MX) ? h[i][i + 1 < MX ? i + 1 : i] : T(0);
-        u2[i] = (i + 2 < MX) ? h[i][i + 2 < MX ? i + 2 : i] : T(0);
+        u1[i] = l[i];
+        u2[i] = T(0);
     }
     if (WITH_U) {
 #pragma unroll
         for (int i = 0; i < MX; ++i)
 #pragma unroll
-            for (int j = 0; j < MX; ++j) u[i][j] = (i == j) ? T(1) : T(0);
+            for (int j = 0; j < MX; ++j)
+                if (i < n && j < n) u[i][j] = (i == j) ? T(1) : T(0);
     }
 #pragma unroll
     for (int m = MX; m >= 2; --m) {
@@ -753,8 +784,6 @@ __device__ __forceinline__ void qr_explicit_band1(T (&h)[Dim<NT>::MAX][Dim<NT>::
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < MX; ++i) h[i][i] = d[i];
 }
 
 // the same shift for the fast sweeps: hardware sqrt / rcp (a shift only steers the iteration)
@@ -776,25 +805,23 @@ __device__ __forceinline__ T wilkinson_fast1(T h0, T h1, T b)
 
 // One explicitly shifted QR step T <- R Q + sigma on the leading m x m block of a SYMMETRIC
 // TRIDIAGONAL matrix, the fast sweeps' form of `rq_step1(..., sym = true)`: the same rotations
-// (c_k, s_k) and, in exact arithmetic, the same T' -- but only the diagonal and the sub-diagonal
+// (c_k, s_k) and, in exact arithmetic, the same T' -- but only the diagonal d and the sub-diagonal e
 // are carried (11 operations per rotation instead of six 4-operation row / column rotations):
 //   p_0 = d_0 - sigma, q_0 = e_0;   (C_k, S_k, r_k) rotate (p_k, e_k) onto (r_k, 0);
 //   u_k = C_k q_k + S_k (d_{k+1} - sigma);   p_{k+1} = C_k (d_{k+1} - sigma) - S_k q_k;   q_{k+1} = C_k e_{k+1};
 //   d'_k = C_{k-1} C_k r_k + S_k u_k + sigma;   e'_{k-1} = S_{k-1} r_k;   d'_{m-1} = C_{m-2} p_{m-1} + sigma.
-// (derivation and a numerical check against the explicit form: DESIGN.md section 4.2).  The upper
-// sub-diagonal is kept equal to the lower one so that the storage stays a symmetric matrix.
-template <typename T, int NT, bool WITH_U>
-__device__ __forceinline__ void tri_sweep_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                                T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m, T sigma)
+// (derivation and a numerical check against the explicit form: DESIGN.md section 4.2)
+template <typename T, int NT, bool WITH_U, class MU>
+__device__ __forceinline__ void tri_sweep_fast1(T (&d)[Dim<NT>::MAX], T (&e)[Dim<NT>::MAX], MU &u, int n, int m, T sigma)
 {
     constexpr int MX = Dim<NT>::MAX;
-    T p = h[0][0] - sigma, q = h[1][0];
+    T p = d[0] - sigma, q = e[0];
     T cprev = T(1), sprev = T(0);
 #pragma unroll
     for (int k = 0; k < MX - 1; ++k) {
         if (k < m - 1) {
-            const T b = h[k + 1][k];
-            const T a1 = h[k + 1][k + 1] - sigma;
+            const T b = e[k];
+            const T a1 = d[k + 1] - sigma;
             T c, sr; // the reference's convention: sr = -S
             givens_fast1(p, b, c, sr);
             const T S = -sr;
@@ -803,13 +830,9 @@ __device__ __forceinline__ void tri_sweep_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MA
             const T pn = fma_t(c, a1, -(S * q));
             T qn = T(0);
             if (k + 2 < MX)
-                if (k + 2 < m) qn = c * h[k + 2][k + 1];
-            h[k][k] = fma_t(c * cprev, r, S * uk) + sigma;
-            if (k > 0) {
-                const T e = sprev * r;
-                h[k][k - 1] = e;
-                h[k - 1][k] = e;
-            }
+                if (k + 2 < m) qn = c * e[k + 1];
+            d[k] = fma_t(c * cprev, r, S * uk) + sigma;
+            if (k > 0) e[k - 1 < 0 ? 0 : k - 1] = sprev * r;
             if (WITH_U) {
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
@@ -821,10 +844,8 @@ __device__ __forceinline__ void tri_sweep_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MA
             sprev = S;
         }
     }
-    const T e = sprev * p;
-    h[m - 1][m - 1] = fma_t(cprev, p, sigma);
-    h[m - 1][m - 2] = e;
-    h[m - 2][m - 1] = e;
+    d[m - 1] = fma_t(cprev, p, sigma);
+    e[m - 2] = sprev * p;
 }
 
 // The last stage of the deflation (m == 2) in the fast sweeps: the leading 2 x 2 block [a b; b d]
@@ -835,12 +856,11 @@ __device__ __forceinline__ void tri_sweep_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MA
 // b == 0 gives t = +-0 and (c, s) = (1, 0) exactly: a diagonal block comes back bit for bit.
 // Lanes whose delta^2 + b^2 is outside the safe range of the hardware rsqrt (0, denormal, inf, NaN)
 // are left untouched and reported: they take the iterative path.
-template <typename T, int NT, bool WITH_U>
-__device__ __forceinline__ bool jacobi2_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                              int n)
+template <typename T, int NT, bool WITH_U, class MU>
+__device__ __forceinline__ bool jacobi2_fast1(T (&dg)[Dim<NT>::MAX], T (&e)[Dim<NT>::MAX], MU &u, int n)
 {
     constexpr int MX = Dim<NT>::MAX;
-    const T a = h[0][0], d = h[1][1], b = h[1][0];
+    const T a = dg[0], d = dg[1], b = e[0];
     const T dl = (d - a) * T(0.5);
     const T r2 = fma_t(dl, dl, b * b);
     const bool ok = r2 > FastRange<T>::lo && r2 < FastRange<T>::hi;
@@ -848,10 +868,9 @@ __device__ __forceinline__ bool jacobi2_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX]
     T inv = hw_rcp(den);
     inv = fma_t(fma_t(-den, inv, T(1)), inv, inv);
     const T t = ((dl < T(0)) ? -b : b) * inv;
-    h[0][0] = ok ? fma_t(-t, b, a) : a;
-    h[1][1] = ok ? fma_t(t, b, d) : d;
-    h[1][0] = ok ? T(0) : b;
-    h[0][1] = h[1][0];
+    dg[0] = ok ? fma_t(-t, b, a) : a;
+    dg[1] = ok ? fma_t(t, b, d) : d;
+    e[0] = ok ? T(0) : b;
     if (WITH_U) {
         T c = rsq_nr(fma_t(t, t, T(1)));
         T s = t * c;
@@ -864,58 +883,52 @@ __device__ __forceinline__ bool jacobi2_fast1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX]
     return ok;
 }
 
-// _qr_explicit(_vectors)_jit_ :572-656 with sym = True; convergence per lane (Q9)
-template <typename T, int NT, bool WITH_U, bool FAST = false>
-__device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                             T (&u)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int max_iter, double tol)
+// the fast sweeps of eig_sym (policy above) on band storage d, e; convergence per lane (Q9)
+template <typename T, int NT, bool WITH_U, class MU>
+__device__ __forceinline__ void qr_fast_band1(T (&d)[Dim<NT>::MAX], T (&e)[Dim<NT>::MAX], MU &u, int n, int max_iter,
+                                              double tol)
 {
-#pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
-    constexpr bool FM = FAST && FastSweeps<T>::on;
-    if constexpr (!FM) { // the reference's operation order (the default): its own loop on band storage
-        qr_explicit_band1<T, NT, WITH_U>(h, u, n, max_iter, tol);
-    } else {
-        // The reference deflates when e^2 < tol (d0^2 + d1^2) with tol = 1e-32 by default: |e| < 1e-16 |d|,
-        // the working precision of float64 -- but eight orders below float32's, where it costs one more
-        // sweep per eigenvalue just to square an off-diagonal that is already below half an ulp.  The fast
-        // sweeps floor the tolerance at the working precision of the dtype, |e| <= eps/4 |d| (the neglected
-        // entry moves an eigenvalue by at most |e|: a quarter of an ulp); a larger caller tolerance is kept.
-        const double floor_ = sizeof(T) == 4 ? 0x1p-52 : 0x1p-110; // (eps / 4)^2, eps = 2^-24 / 2^-53
-        tol = tol > floor_ ? tol : floor_;
-        const T tol_t = (T)tol, stuck_t = (T)(tol * 1e-3);
-        if (WITH_U) {
+    // The reference deflates when e^2 < tol (d0^2 + d1^2) with tol = 1e-32 by default: |e| < 1e-16 |d|,
+    // the working precision of float64 -- but eight orders below float32's, where it costs one more
+    // sweep per eigenvalue just to square an off-diagonal that is already below half an ulp.  The fast
+    // sweeps floor the tolerance at the working precision of the dtype, |e| <= eps/4 |d| (the neglected
+    // entry moves an eigenvalue by at most |e|: a quarter of an ulp); a larger caller tolerance is kept.
+    const double floor_ = sizeof(T) == 4 ? 0x1p-52 : 0x1p-110; // (eps / 4)^2, eps = 2^-24 / 2^-53
+    tol = tol > floor_ ? tol : floor_;
+    const T tol_t = (T)tol, stuck_t = (T)(tol * 1e-3);
+    if (WITH_U) {
 #pragma unroll
-            for (int i = 0; i < MX; ++i)
+        for (int i = 0; i < MX; ++i)
 #pragma unroll
-                for (int j = 0; j < MX; ++j) u[i][j] = (i == j) ? T(1) : T(0);
-        }
+            for (int j = 0; j < MX; ++j)
+                if (i < n && j < n) u[i][j] = (i == j) ? T(1) : T(0);
+    }
 #pragma unroll
-        for (int m = MX; m >= 2; --m) {
-            if (m <= n) {
-                int iters = max_iter;
-                if (m == 2 && max_iter > 0)
-                    if (jacobi2_fast1<T, NT, WITH_U>(h, u, n)) iters = 0;
-                T ratio_prev = T(0);
-                for (int it = 0; it < iters; ++it) {
-                    const T sigma = wilkinson_fast1(h[m - 2][m - 2], h[m - 1][m - 1], h[m - 1][m - 2]);
-                    tri_sweep_fast1<T, NT, WITH_U>(h, u, n, m, sigma);
-                    const T bb = fabs_(h[m - 1][m - 2]), a0 = fabs_(h[m - 1][m - 1]), a1 = fabs_(h[m - 2][m - 2]);
-                    const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
-                    // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
-                    // more: a zero off-diagonal (diagonal or zero blocks, padding lanes of the last
-                    // tile) or NaNs would otherwise spin through all max_iter identical iterations
-                    const bool conv = sos_lower <= tol_t * sos_diag; // in T: tol_t >= (eps/4)^2 is a normal number
-                    if (conv || sos_lower != sos_lower) {
-#pragma unroll
-                        for (int j = 0; j < m - 1; ++j) h[m - 1][j] = T(0);
-                        break;
-                    }
-                    if constexpr (!WITH_U) { // the "stuck" exit :648-653 in T (the ratio only detects a fixed point)
-                        const T ratio = sos_lower * hw_rcp(sos_diag);
-                        const T dif = fabs_(ratio_prev - ratio);
-                        if (ratio_prev != T(0) && dif < stuck_t * ratio_prev) break;
-                        ratio_prev = ratio;
-                    }
+    for (int m = MX; m >= 2; --m) {
+        if (m <= n) {
+            int iters = max_iter;
+            if (m == 2 && max_iter > 0)
+                if (jacobi2_fast1<T, NT, WITH_U>(d, e, u, n)) iters = 0;
+            T ratio_prev = T(0);
+            for (int it = 0; it < iters; ++it) {
+                const T sigma = wilkinson_fast1(d[m - 2], d[m - 1], e[m - 2]);
+                tri_sweep_fast1<T, NT, WITH_U>(d, e, u, n, m, sigma);
+                const T bb = fabs_(e[m - 2]), a0 = fabs_(d[m - 1]), a1 = fabs_(d[m - 2]);
+                const T sos_lower = bb * bb, sos_diag = a0 * a0 + a1 * a1;
+                // `<=` (upstream: `<`) and the NaN test only matter when nothing can change any
+                // more: a zero off-diagonal (diagonal or zero blocks, padding lanes of the last
+                // tile) or NaNs would otherwise spin through all max_iter identical iterations
+                const bool conv = sos_lower <= tol_t * sos_diag; // in T: tol_t >= (eps/4)^2 is a normal number
+                if (conv || sos_lower != sos_lower) {
+                    e[m - 2] = T(0);
+                    break;
+                }
+                if constexpr (!WITH_U) { // the "stuck" exit :648-653 in T (the ratio only detects a fixed point)
+                    const T ratio = sos_lower * hw_rcp(sos_diag);
+                    const T dif = fabs_(ratio_prev - ratio);
+                    if (ratio_prev != T(0) && dif < stuck_t * ratio_prev) break;
+                    ratio_prev = ratio;
                 }
             }
         }
@@ -923,14 +936,13 @@ __device__ __forceinline__ void qr_explicit1(T (&h)[Dim<NT>::MAX][Dim<NT>::MAX],
 }
 
 // apply P = I - 2 w w^T (w of length m, acting on the trailing m rows) from the left
-// householder_apply_ :72-106, side='left'
-template <typename T, int NT, bool FAST = false>
-__device__ __forceinline__ void reflect_left1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], int n, int m,
-                                              const T (&w)[Dim<NT>::MAX])
+// householder_apply_ :72-106, side='left'.  K0 = n - m, the first row touched, is a LITERAL for the caller
+// (eig_sym1: reflector k acts on rows k+1..), so that w is indexed by literals.
+template <typename T, int NT, bool FAST = false, class MA>
+__device__ __forceinline__ void reflect_left1(MA &a, int n, int k0, const T (&w)[Dim<NT>::MAX])
 {
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
-    const int k0 = n - m;
     if constexpr (FAST) { // eig_sym's fast arithmetic: the same update contracted to fma
 #pragma unroll
         for (int c = 0; c < MX; ++c)
@@ -959,16 +971,25 @@ __device__ __forceinline__ void reflect_left1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX]
         }
 }
 
-// _fwd_eig_sym :665-681.  `a` holds the symmetric input (the requested triangle already
-// mirrored); on return vals = diagonal, and for WITH_U the columns of u are the eigenvectors.
-template <typename T, int NT, bool WITH_U, bool FAST = false>
-__device__ __forceinline__ void eig_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (&u)[Dim<NT>::MAX][Dim<NT>::MAX],
-                                         int n, int max_iter, double tol)
+// _fwd_eig_sym :665-681.  `a` holds the symmetric input in its LOWER triangle (the caller mirrors the
+// requested one on load; the upper triangle is never read); `up` is where the reflectors go (WITH_U).  On
+// return vals = eigenvalues in deflation order, and for WITH_U the columns of u are the eigenvectors.
+template <typename T, int NT, bool WITH_U, bool FAST = false, class MA, class MU, class MP>
+__device__ __forceinline__ void eig_sym1(MA &a, MU &u, MP &up, T (&vals)[Dim<NT>::MAX], int n, int max_iter, double tol)
 {
     constexpr int MX = Dim<NT>::MAX;
-    T up[MX][MX];
-    hessenberg_sym1<T, NT, WITH_U, FAST, !FAST>(a, n, up);
-    qr_explicit1<T, NT, WITH_U, FAST>(a, u, n, max_iter, tol);
+    constexpr bool FM = FAST && FastSweeps<T>::on;
+    hessenberg_sym1<T, NT, WITH_U, FAST, !FAST, false>(a, n, up);
+    T e[MX];
+#pragma unroll
+    for (int i = 0; i < MX; ++i) {
+        vals[i] = (i < n) ? a[i][i] : T(0);
+        e[i] = T(0);
+        if (i + 1 < MX)
+            if (i + 1 < n) e[i] = a[i + 1 < MX ? i + 1 : i][i];
+    }
+    if constexpr (FM) qr_fast_band1<T, NT, WITH_U>(vals, e, u, n, max_iter, tol);
+    else qr_explicit_band1<T, NT, WITH_U>(vals, e, u, n, max_iter, tol);
     if (WITH_U) {
         // householder_apply_(u, q, side='left', inverse=True): reflectors in reverse order
 #pragma unroll
@@ -976,8 +997,8 @@ __device__ __forceinline__ void eig_sym1(T (&a)[Dim<NT>::MAX][Dim<NT>::MAX], T (
             if (k < n - 2) {
                 T w[MX];
 #pragma unroll
-                for (int r = 0; r < MX; ++r) w[r] = up[k][r];
-                reflect_left1<T, NT, FAST && FastSweeps<T>::on>(u, n, n - k - 1, w);
+                for (int r = 0; r < MX; ++r) w[r] = (r < n - 1 - k) ? up[k][r] : T(0);
+                reflect_left1<T, NT, FM>(u, n, k + 1, w);
             }
     }
 }

@@ -252,16 +252,29 @@ struct LongDigits {
     static __host__ __device__ constexpr int shift(int p) { return p + 1 < passes ? bits - kLongBits * (p + 1) : 0; }
 };
 
-// pick_digit for NB consecutive bins per lane (64 * NB bins)
-template <int NB>
-__device__ __forceinline__ unsigned pick_digit_n(const unsigned (&cnt)[NB], unsigned long long &k)
+__device__ __forceinline__ unsigned long long wave_excl_scan64(unsigned long long v)
 {
     const int lane = threadIdx.x & 63;
-    unsigned tot, mine = 0;
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned lo = __shfl_up((unsigned)s, off, 64), hi = __shfl_up((unsigned)(s >> 32), off, 64);
+        if (lane >= off) s += ((unsigned long long)hi << 32) | lo;
+    }
+    return s - v;
+}
+
+// pick_digit for NB consecutive bins per lane (64 * NB bins) of a LONG row: counts in 64 bits (a single row
+// can hold 2^33 elements -- the dim=None median of a 32 GiB tensor -- and constant data puts them all in one bin)
+template <int NB>
+__device__ __forceinline__ unsigned pick_digit_n(const unsigned long long (&cnt)[NB], unsigned long long &k)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long mine = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) mine += cnt[b];
-    const unsigned before = wave_excl_scan(mine, tot);
-    const bool here = (unsigned long long)before <= k && k < (unsigned long long)before + mine;
+    const unsigned long long before = wave_excl_scan64(mine);
+    const bool here = before <= k && k < before + mine;
     const unsigned long long m = __ballot(here);
     const int src = m ? __builtin_ctzll(m) : 63; // k < total always: exactly one lane
     unsigned digit = 0;
@@ -297,7 +310,8 @@ static_assert(sizeof(RowState) == 40, "workspace layout");
 
 template <typename T>
 __global__ __launch_bounds__(256) void median_hist_kernel(const T *__restrict__ x, int64_t red, int64_t chunk, int pass,
-                                                          const RowState *__restrict__ st, unsigned *__restrict__ ghist,
+                                                          const RowState *__restrict__ st,
+                                                          unsigned long long *__restrict__ ghist,
                                                           unsigned long long *__restrict__ gnan)
 {
     using K = Key<T>;
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const T *__restrict__ 
 #pragma unroll
     for (int b = 0; b < kLongBins / 256; ++b) {
         const unsigned c = hist[threadIdx.x + 256 * b];
-        if (c) atomicAdd(&ghist[row * kLongBins + threadIdx.x + 256 * b], c);
+        if (c) atomicAdd(&ghist[row * kLongBins + threadIdx.x + 256 * b], (unsigned long long)c); // (a block's chunk < 2^32)
     }
     if (first_pass && threadIdx.x == 0 && nan_s) atomicAdd(&gnan[row], (unsigned long long)nan_s);
 }
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(256) void median_hist_kernel(const T *__restrict__ 
 // one wavefront per row: choose the digit of this pass, clear the histogram for the next one
 template <typename T>
 __global__ __launch_bounds__(64) void median_pick_kernel(int64_t red, int pass, int omitnan, RowState *__restrict__ st,
-                                                         unsigned *__restrict__ ghist,
+                                                         unsigned long long *__restrict__ ghist,
                                                          unsigned long long *__restrict__ gnan, T *__restrict__ val)
 {
     using K = Key<T>;
@@ -374,9 +388,9 @@ __global__ __launch_bounds__(64) void median_pick_kernel(int64_t red, int pass, 
         s.k = count ? (count - 1) / 2 : 0;
         s.first = red; // "not found yet" for the index pass
     }
-    unsigned *gh = ghist + row * kLongBins + NB * lane;
+    unsigned long long *gh = ghist + row * kLongBins + NB * lane;
     if (!s.want_nan) {
-        unsigned cnt[NB];
+        unsigned long long cnt[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) cnt[b] = gh[b];
         unsigned long long k = s.k;
@@ -428,6 +442,7 @@ __global__ void median_store_index_kernel(int64_t rows, int64_t red, const RowSt
 
 constexpr int kShortMax = 1024;
 constexpr int64_t kLaneMinRows = 4096; // below this the rows do not fill the lanes of the chip: the group kernel
+constexpr int64_t kLanePadMinRows = 32768; // padded rows: one wavefront per SIMD (256+ registers) -- 64 Ki lanes fill the chip once
 
 static int64_t chunk_of(int64_t rows, int64_t red)
 {
@@ -455,6 +470,24 @@ static int lane_any(int dt, int red, int omitnan, int64_t rows, int64_t inner, c
     }
 }
 
+// one PADDED row per lane: lengths LaneMax+1 .. 2 LaneMax, bucket = part (nfm_reduce_median_lane.hip)
+template <typename T>
+static int lane_pad_any(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, void *stream)
+{
+    constexpr int step = LaneMax<T>::value / kLaneParts; // 16 / 8
+    const int dt = sizeof(T) == 4 ? NFM_F32 : NFM_F64;
+    switch ((red - LaneMax<T>::value - 1) / step) {
+    case 0: return lane_part0(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    case 1: return lane_part1(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    case 2: return lane_part2(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    case 3: return lane_part3(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    case 4: return lane_part4(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    case 5: return lane_part5(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    case 6: return lane_part6(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    default: return lane_part7(dt, -red, omitnan, rows, 1, x, val, idx, stream);
+    }
+}
+
 template <typename T>
 static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, size_t ws_bytes, void *val, void *idx,
                void *stream)
@@ -462,6 +495,9 @@ static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (red >= 2 && red <= LaneMax<T>::value && rows >= kLaneMinRows && reinterpret_cast<uintptr_t>(x) % sizeof(T) == 0)
         return lane_any(sizeof(T) == 4 ? NFM_F32 : NFM_F64, (int)red, omitnan, rows, 1, x, val, idx, stream);
+    if (red > LaneMax<T>::value && red <= LanePadMax<T>::value && rows >= kLanePadMinRows &&
+        reinterpret_cast<uintptr_t>(x) % sizeof(T) == 0)
+        return lane_pad_any<T>((int)red, omitnan, rows, x, val, idx, stream);
     if (red <= 32) {
         const int G = red <= 8 ? 8 : (red <= 16 ? 16 : 32);
         const int64_t nblk = (rows + 4 * (64 / G) - 1) / (4 * (64 / G));
@@ -493,11 +529,11 @@ static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, 
         return launch_status();
     }
     if (rows > 65535) return NFM_ESIZE; // grid.y; the facade splits (long rows are few)
-    const size_t need = (size_t)rows * (sizeof(RowState) + kLongBins * sizeof(unsigned) + sizeof(unsigned long long));
+    const size_t need = (size_t)rows * (sizeof(RowState) + kLongBins * sizeof(unsigned long long) + sizeof(unsigned long long));
     if (ws == nullptr || ws_bytes < need) return NFM_EINVAL;
     RowState *st = static_cast<RowState *>(ws);
     unsigned long long *gnan = reinterpret_cast<unsigned long long *>(st + rows);
-    unsigned *ghist = reinterpret_cast<unsigned *>(gnan + rows);
+    unsigned long long *ghist = gnan + rows;
     hipError_t e = hipMemsetAsync(ws, 0, need, s);
     if (e != hipSuccess) return (int)e;
     const int64_t chunk = chunk_of(rows, red);
@@ -528,7 +564,7 @@ extern "C" {
 size_t nfm_reduce_median_workspace_bytes(int64_t rows, int64_t red)
 {
     if (rows <= 0 || red <= med::kShortMax) return 0;
-    return (size_t)rows * (sizeof(med::RowState) + med::kLongBins * sizeof(unsigned) + sizeof(unsigned long long));
+    return (size_t)rows * (sizeof(med::RowState) + med::kLongBins * sizeof(unsigned long long) + sizeof(unsigned long long));
 }
 
 int nfm_reduce_median_lane_max(int dtype)

@@ -47,6 +47,12 @@ template <typename T>
 struct LaneMax {
     static constexpr int value = sizeof(T) == 4 ? 128 : 64;
 };
+// rows up to twice that length are sorted by one lane too, padded to one of 8 bucket lengths per dtype
+// (median_lane_pad_kernel): bucket b lives in part b and is reached with red passed NEGATED
+template <typename T>
+struct LanePadMax {
+    static constexpr int value = 2 * LaneMax<T>::value;
+};
 constexpr int kLaneParts = 8; // the lane kernels are compiled in 8 objects: row lengths by their residue mod 8
 
 // part `p` serves the row lengths red with red % 8 == p; returns NFM_EINVAL for a length it does not hold.

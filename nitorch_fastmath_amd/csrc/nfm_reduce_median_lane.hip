@@ -13,7 +13,7 @@ namespace nfm {
 namespace med {
 
 // ---------------------------------------------------------------------------------------------
-// rows of 2..128 elements (float64: 2..64), ONE ROW PER LANE: the rows of a contiguous (rows, RED) array are
+// rows of 2..128 elements (float64: 2..64), ONE ROW PER LANE (longer ones, up to twice that: below): the rows of a contiguous (rows, RED) array are
 // records like the small matrices of the other kernels -- the workgroup streams its TILE * RED elements with
 // 16-byte loads through the LDS transpose (TileIO), every lane picks up its row, sorts the RED keys
 // in registers with Batcher's odd-even merge network (compile-time indices: v_min_u32 / v_max_u32 per
@@ -82,17 +82,23 @@ struct MergeExchange {
     }
 };
 
-template <typename U, int RED, size_t... I>
+// (applied in chunks of 1024 comparators: a fold expression nests once per operand, and the front end stops at 2048)
+template <typename U, int RED, size_t OFF, size_t... I>
 __device__ __forceinline__ void apply_network(Keys<U, RED> &s, std::index_sequence<I...>)
 {
     constexpr auto net = MergeExchange<RED>::list();
-    (cmpxchg(s.at(net.a[I]), s.at(net.b[I])), ...);
+    (cmpxchg(s.at(net.a[OFF + I]), s.at(net.b[OFF + I])), ...);
 }
 
-template <typename U, int RED>
+template <typename U, int RED, size_t OFF = 0>
 __device__ __forceinline__ void sort_network(Keys<U, RED> &s)
 {
-    apply_network<U, RED>(s, std::make_index_sequence<(size_t)MergeExchange<RED>::count()>{});
+    constexpr size_t total = (size_t)MergeExchange<RED>::count();
+    if constexpr (OFF < total) {
+        constexpr size_t n = total - OFF < 1024 ? total - OFF : 1024;
+        apply_network<U, RED, OFF>(s, std::make_index_sequence<n>{});
+        sort_network<U, RED, OFF + n>(s);
+    }
 }
 
 constexpr int64_t kMidGrid2D = 2048; // middle-dim layout: planes at least this wide take the 2-D grid
@@ -121,7 +127,8 @@ __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(
     // row of this lane, and for the middle-dim layout its (o, i).  No 64-bit division (a 64-iteration
     // software loop per lane: it cost 3x the rest of the kernel): wide planes take a 2-D grid, blockIdx.y
     // + 65535 blockIdx.z = o; narrow ones (inner < kMidGrid2D) a 32-bit division (rows < 2^31 there).
-    const bool grid2d = mid && gridDim.y * gridDim.z > 1;
+    const bool grid2d = mid && inner >= kMidGrid2D; // the launcher's rule (a single outer index is a 2-D grid too:
+                                                    // the 32-bit division below is for rows < 2^31 only)
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     int64_t row = tile0 + threadIdx.x, mo = 0, mi = 0;
     bool live = row < rows;
@@ -223,6 +230,92 @@ static int run_lane(int omitnan, int64_t rows, int64_t inner, const void *x, voi
     return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// rows of LaneMax+1 .. 2 LaneMax elements (float32: 129..256, float64: 65..128), still ONE ROW PER LANE: the
+// row is padded to the next BUCKET length (a multiple of 16 / 8 elements: eight buckets per dtype instead of
+// 128 / 64 more instantiations) with keys that sort after everything, the rank is taken among the `red` real
+// ones.  A 2 Ki-element LDS histogram kernel served these lengths before, at 0.5-1.4 TB/s (LDS atomics); the
+// network costs ~34 v_min/v_max per key and no cross-lane traffic.  The lane fetches its row itself with
+// element-aligned 16-byte loads (no LDS image: 64 rows of up to 1 KiB would be the whole LDS of a
+// workgroup; consecutive loads of a lane walk the same cache lines), the index search reads it again.
+template <typename T>
+struct PadStep {
+    static constexpr int value = sizeof(T) == 4 ? 16 : 8;
+};
+template <typename T, int RED> // RED: bucket length; RED - PadStep < red <= RED
+__global__ __launch_bounds__(64) void median_lane_pad_kernel(const T *__restrict__ x, int64_t rows, int red, int omitnan,
+                                                             T *__restrict__ val, int64_t *__restrict__ idx)
+{
+    using K = Key<T>;
+    using U = typename K::U;
+    using VG = typename VecOf<T>::gtype;
+    constexpr int V = VecOf<T>::N;
+    constexpr int SURE = RED - PadStep<T>::value; // elements every row of this bucket has
+    static_assert(SURE % V == 0 && SURE > 0, "buckets are multiples of the pad step");
+    const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = row < rows;
+    const T *own = x + (live ? row : rows - 1) * (int64_t)red;
+    Keys<U, RED> s;
+    unsigned nan = 0;
+#pragma unroll
+    for (int i = 0; i < SURE; i += V) {
+        const VG v = NFM_LDG(reinterpret_cast<const VG *>(own + i));
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            s.at(i + q) = K::of(v[q]);
+            nan += (v[q] != v[q]) ? 1u : 0u;
+        }
+        if (i % 32 == 32 - V) __builtin_amdgcn_sched_barrier(0); // keep the loads from piling up ahead of the conversions
+    }
+#pragma unroll
+    for (int i = SURE; i < RED; ++i) {
+        if (i < red) { // uniform
+            const T v = NFM_LDG(own + i);
+            s.at(i) = K::of(v);
+            nan += (v != v) ? 1u : 0u;
+        } else {
+            s.at(i) = ~U(0); // padding: the NaN key, sorts last (not counted in `nan`)
+        }
+    }
+    sort_network<U, RED>(s);
+    const unsigned count = omitnan ? (unsigned)red - nan : (unsigned)red;
+    const bool want_nan = (!omitnan && nan > 0) || count == 0;
+    const unsigned k = count ? (count - 1) / 2 : 0;
+    // rank k of the sorted keys; k < red <= RED and k >= (RED - PadStep - 1) / 2 - ... : only ranks a row of this
+    // bucket can ask for are looked at (omitnan lowers the rank by up to half the NaN count)
+    U chosen = s.at(0);
+#pragma unroll
+    for (int i = 1; i <= (RED - 1) / 2; ++i) chosen = (k == (unsigned)i) ? s.at(i) : chosen;
+    if (want_nan) chosen = ~U(0);
+    if (live) {
+        val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
+        if (idx != nullptr) { // uniform: first position holding the chosen key (a NaN result: the first NaN)
+            int first = 0;
+            for (int i = red - 1; i >= 0; --i) first = (K::of(own[i]) == chosen) ? i : first;
+            idx[row] = first;
+        }
+    }
+}
+
+template <typename T, int RED>
+static int run_lane_pad(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
+{
+    const int64_t nblk = (rows + 63) / 64;
+    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    hipLaunchKernelGGL((median_lane_pad_kernel<T, RED>), dim3((unsigned)nblk), dim3(64), 0, s, static_cast<const T *>(x),
+                       rows, red, omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx));
+    return launch_status();
+}
+
+// bucket b = 0..7 of dtype T: lengths LaneMax + b * step + 1 .. LaneMax + (b + 1) * step; part p holds bucket p
+template <typename T>
+static int lane_pad_bucket(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
+{
+    constexpr int RED = LaneMax<T>::value + (NFM_MED_LANE_PART + 1) * PadStep<T>::value;
+    if (red <= RED - PadStep<T>::value || red > RED) return NFM_EINVAL;
+    return run_lane_pad<T, RED>(red, omitnan, rows, x, val, idx, s);
+}
+
 // the lengths of this part, RED = first, first + 8, ... <= LaneMax
 template <typename T, int RED>
 static int lane_chain(int red, int omitnan, int64_t rows, int64_t inner, const void *x, void *val, void *idx,
@@ -243,6 +336,10 @@ int NFM_MED_CAT(lane_part, NFM_MED_LANE_PART)(int dtype, int red, int omitnan, i
 {
     constexpr int first = NFM_MED_LANE_PART >= 2 ? NFM_MED_LANE_PART : NFM_MED_LANE_PART + kLaneParts; // lengths start at 2
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (red < 0) { // padded rows (contiguous only): -red in this part's bucket (lane_pad_any picks the part)
+        return dtype == NFM_F32 ? lane_pad_bucket<float>(-red, omitnan, rows, x, val, idx, s)
+                                : lane_pad_bucket<double>(-red, omitnan, rows, x, val, idx, s);
+    }
     return dtype == NFM_F32 ? lane_chain<float, first>(red, omitnan, rows, inner, x, val, idx, s)
                             : lane_chain<double, first>(red, omitnan, rows, inner, x, val, idx, s);
 }

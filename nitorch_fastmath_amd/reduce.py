@@ -343,7 +343,7 @@ def median(input, dim=None, keepdim=False, omitnan=False, inplace=False, return_
         x = xg.detach()
         if not x.is_contiguous():
             x = x.contiguous()
-    step = rows if red <= 1024 else 65535          # long rows: grid.y bound of the histogram passes
+    step = rows if red <= 1024 else 16384          # long rows: grid.y bound of the histogram passes; 16 KiB of 64-bit bins per row
     for lo in ([] if rows_done else range(0, rows, builtins.max(step, 1))):
         hi = builtins.min(rows, lo + step)
         ws, wsn = _workspace(dev, L.nfm_reduce_median_workspace_bytes(hi - lo, red))

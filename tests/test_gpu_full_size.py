@@ -102,3 +102,25 @@ def test_reductions_full_size_c4(dev):
     v, i = R.nanmax(xm, dim=1, return_indices=True)
     assert float(v.max()) == mx
     assert torch.equal(xm.gather(1, i.unsqueeze(1)).squeeze(1), v)    # the index points at the value
+
+
+def test_median_of_a_row_longer_than_2_pow_32(dev):
+    """`median(x)` with dim=None on more than 2^32 elements (the C4 tensor has 2^33): the radix selection of a
+    long row counts in 64 bits.  Constant data is the hard case -- every element of a pass lands in ONE
+    histogram bin, whose count (and the scan over the bins) passes 2^32; 32-bit counters wrapped and
+    returned another element."""
+    from nitorch_fastmath_amd import reduce as R
+    n = (1 << 32) + 12345
+    _need(dev, 24)
+    x = torch.zeros(n, device=dev)
+    x[:1000] = -1.0
+    x[-7:] = 2.0
+    assert float(R.median(x)) == 0.0
+    v, i = R.median(x, return_indices=True)
+    assert float(v) == 0.0 and int(i) == 1000                 # first position holding the value
+    x[1000:1000 + (1 << 31)] = -3.0                           # now 2^31 + 1000 of 2^32 + 12345 are below 0: still 0
+    assert float(R.median(x)) == 0.0
+    x[1000:1000 + (1 << 31) + 8000] = -3.0                    # more than half below: the median moves
+    assert float(R.median(x)) == -3.0
+    x[5] = float('nan')
+    assert torch.isnan(R.median(x)) and float(R.median(x, omitnan=True)) == -3.0

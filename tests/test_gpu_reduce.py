@@ -502,6 +502,42 @@ def test_median_row_per_lane(dev, oracle, dn):
 
 
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_median_padded_row_per_lane(dev, oracle, dn):
+    """rows of 129..256 (float64: 65..128) elements in batches of >= 32768 rows: one PADDED row per lane
+    (median_lane_pad_kernel: the row is padded to the next bucket length with keys that sort last) -- both
+    ends and the middle of every bucket, NaNs kept and omitted, all-NaN rows, infinities, signed zeros, ties;
+    values and first-position indices equal to the oracle's bit for bit, and to the few-rows kernel's"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    lo, step = (128, 16) if dn == 'f32' else (64, 8)
+    lengths = sorted({lo + b * step + d for b in range(8) for d in (1, step // 2, step)} | {2 * lo + 1})
+    for red in lengths:                                   # the last one is past the limit: the wavefront-per-row kernel
+        rng = np.random.default_rng(3000 + red)
+        rows = 32768 + 64 + 29
+        x = rng.standard_normal((rows, red)).astype(dtype)
+        x[::7] = np.round(x[::7] * 2) / 2                                   # ties
+        x[rng.random((rows, red)) < 0.02] = np.nan
+        x[5] = np.nan                                                       # all NaN
+        x[6, 0], x[6, -1] = np.inf, -np.inf
+        x[8] = 0.0
+        x[8, ::2] = -0.0                                                    # signed zeros only
+        x[9, :-1] = np.nan                                                  # one value left
+        xd = t(x, dev)
+        for omit in (False, True):
+            v, i = R().median(xd, dim=1, omitnan=omit, return_indices=True)
+            v0 = R().median(xd, dim=1, omitnan=omit)
+            rv, ri = oracle.median(x, 1, omitnan=omit)
+            v, i, v0 = v.cpu().numpy(), i.cpu().numpy(), v0.cpu().numpy()
+            assert np.array_equal(v.view(np.uint8), v0.view(np.uint8))      # with and without the index output
+            nn = ~np.isnan(rv)
+            assert np.array_equal(np.isnan(v), np.isnan(rv)), (red, omit)
+            assert np.array_equal(v[nn].view(np.uint8), rv[nn].view(np.uint8)), (red, omit)
+            assert np.array_equal(i, ri), (red, omit)
+            few = R().median(xd[:100], dim=1, omitnan=omit, return_indices=True)     # few rows: the group kernel
+            assert np.array_equal(few[0].cpu().numpy().view(np.uint8), v[:100].view(np.uint8))
+            assert np.array_equal(few[1].cpu().numpy(), i[:100])
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
 def test_median_middle_dim_without_transpose(dev, oracle, dn):
     """the channel dim (or a block of adjacent dims) of a contiguous channel-first field: one row per
     lane straight from the (outer, red, inner) layout (nfm_reduce_median_mid) -- same values and indices
