@@ -29,7 +29,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                   4x4 solve, the torch-eager restatement of the reference's op sequence at
                   1 thread and at all threads.
 Other workloads (parity-test configs, for profiling): --workload sym_solve6 | batchinv8 |
-nansum | nanmax | sym_invert3 | eig3.  `--workload null` is the launcher self-test (no
+nansum | nanmax | sym_invert3 | eig3 | eig8.  `--workload null` is the launcher self-test (no
 computation; runs on CPU with --backend gloo).
 """
 import argparse
@@ -264,20 +264,21 @@ def make_workload(name, n_arg, device, rank, layout):
         w.cpu = cpu
         w.cpu_eager = eager_timer(lambda ns: (mat[:ns].cpu(),), 'sym_invert', n)
         w.eager_sizes = (n, n)
-    elif name == 'eig3':
-        n = int(n_arg or 5e7)
+    elif name in ('eig3', 'eig8'):
+        E = 3 if name == 'eig3' else 8
+        n = int(n_arg or (5e7 if E == 3 else 8e6))
         g = torch.Generator(device=device).manual_seed(seed)
-        a = torch.randn(n, 3, 3, device=device, generator=g)
+        a = torch.randn(n, E, E, device=device, generator=g)
         a = a + a.transpose(-1, -2)          # symmetric (Hessian-filter shaped workload)
-        w.units, w.bytes_per_unit, w.dtype = n, (9 + 3) * 4, 'f32'
-        w.desc = f'eig_sym 3x3 symmetric fp32 (eigenvalues), batch {n:.0e}'
-        w.metric, w.unit = '3x3 symmetric eigenvalue problems/sec', 'matrices/s'
+        w.units, w.bytes_per_unit, w.dtype = n, (E * E + E) * 4, 'f32'
+        w.desc = f'eig_sym {E}x{E} symmetric fp32 (eigenvalues), batch {n:.0e}'
+        w.metric, w.unit = f'{E}x{E} symmetric eigenvalue problems/sec', 'matrices/s'
         last = {}
 
         def step():
             last['out'] = N.eig_sym(a, check_finite=False)
         w.step = step
-        w.kernel = 'rec_kernel<float, EigSymOp<float, 3, false>, 1>'
+        w.kernel = f'rec_kernel<float, EigSymOp<float, {E}, false, false>, 1>'
 
         def check():
             import numpy as np

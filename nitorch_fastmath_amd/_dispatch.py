@@ -44,9 +44,15 @@ _cur_device = getattr(torch._C, '_cuda_getDevice', None)
 
 def stream_ptr(device):
     """raw hipStream_t of torch's current stream on `device` (the private accessor is 10x cheaper
-    than building a torch.cuda.Stream object: small batches are launch-bound)"""
+    than building a torch.cuda.Stream object: small batches are launch-bound).  A private accessor that
+    is gone or has changed its signature falls back to the public API; that it still MEANS the same is
+    pinned by tests/test_gpu_streams_graphs.py::test_fast_accessors_agree_with_the_public_api."""
+    global _raw_stream
     if _raw_stream is not None:
-        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+        try:
+            return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+        except (TypeError, RuntimeError):
+            _raw_stream = None
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -63,8 +69,13 @@ _NO_GUARD = _NoGuard()
 
 def on_device(device):
     """device guard for the C-ABI call, skipped when `device` already is the current device"""
-    if _cur_device is not None and device.index is not None and _cur_device() == device.index:
-        return _NO_GUARD
+    global _cur_device
+    if _cur_device is not None and device.index is not None:
+        try:
+            if _cur_device() == device.index:
+                return _NO_GUARD
+        except (TypeError, RuntimeError):
+            _cur_device = None
     return torch.cuda.device(device)
 
 

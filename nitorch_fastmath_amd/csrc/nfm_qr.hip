@@ -11,9 +11,12 @@
 // build in parallel: parts 0..3 hold the entry points and the register kernels of orders 1..8 (one object
 // per group of entry points), parts 4..11 the LDS-resident kernels of orders 9..16 (qr_lds_kernel), one
 // object per (dtype, group of operations): 4 + 4 * f64 + g, g = 0: eig_sym values, 1: eig_sym vectors,
-// 2: hessenberg / qr_hessenberg / householder, 3: hessenberg_sym / rq_hessenberg.
+// 2: hessenberg / qr_hessenberg / householder, 3: hessenberg_sym / rq_hessenberg; parts 12..27 the REGISTER
+// kernels of orders 9..16 (the same Ops as orders 1..8, contiguous operands only), one object per
+// (dtype, order): 12 + 8 * f64 + (N - 9) -- the cases whose matrices fit the 512 registers of a lane
+// (qr_large_fits below, from the compiler's resource reports); the others stay on the LDS kernels.
 #ifndef NFM_QR_PART
-#error "compile with -DNFM_QR_PART=0..11"
+#error "compile with -DNFM_QR_PART=0..27"
 #endif
 
 namespace nfm {
@@ -83,6 +86,9 @@ struct HessOp {
     using RO = Rec<1, N * N + (WITH_U ? upack_len(N) : 0)>;
     using Params = QrParams;
     static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
+    // orders 9..16: 0.6-2 KiB of records per lane -- an LDS image of a 64-lane tile would be most of a CU's LDS
+    // and leave one wavefront per CU; the records are fetched and stored per lane instead (op_no_tile)
+    static constexpr bool kNoTile = N >= 9;
     static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
                                                  T (&o)[RO::Cs], const Params &p)
     {
@@ -117,7 +123,7 @@ struct QrHessOp {
     static constexpr int TILE = pick_tile((RA::C + RO::C) * (int)sizeof(T) + 32);
     // 8 x 8 float64: 1.5 KiB of records per lane, i.e. a 96 KiB LDS image per 64-lane workgroup and one
     // wavefront per CU -- fetched and stored per lane instead (op_no_tile)
-    static constexpr bool kNoTile = (RA::C + RO::C) * (int)sizeof(T) >= 1400;
+    static constexpr bool kNoTile = N >= 9 || (RA::C + RO::C) * (int)sizeof(T) >= 1400;
     static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&)[1], const T (&)[1],
                                                  T (&o)[RO::Cs], const Params &)
     {
@@ -142,6 +148,7 @@ struct RqHessOp {
     using RO = Rec<1, N * N * (WITH_U ? 2 : 1)>;
     using Params = QrParams;
     static constexpr int TILE = pick_tile((RA::C + RB::C + RO::C) * (int)sizeof(T) + 48);
+    static constexpr bool kNoTile = N >= 9; // as HessOp
     static __device__ __forceinline__ void apply(const T (&r)[RA::Cs], const T (&ru)[RB::Cs], const T (&)[1],
                                                  T (&o)[RO::Cs], const Params &p)
     {
@@ -423,11 +430,139 @@ NFM_QR_LDS_DECL(f32, 0) NFM_QR_LDS_DECL(f32, 1) NFM_QR_LDS_DECL(f32, 2) NFM_QR_L
 NFM_QR_LDS_DECL(f64, 0) NFM_QR_LDS_DECL(f64, 1) NFM_QR_LDS_DECL(f64, 2) NFM_QR_LDS_DECL(f64, 3)
 #undef NFM_QR_LDS_DECL
 
+// ---------------------------------------------------------------- orders 9..16 in registers
+// Which (dtype, order, operation) of the orders 9..16 runs as a register kernel: the cases hipcc compiles
+// without a private segment (scripts/survey_qr_large.sh: -Rpass-analysis=kernel-resource-usage of every
+// combination; registers beyond the 256 architectural ones are parked in the 256 accumulation registers of the
+// lane, which costs a move each way but no memory).  Everything else runs from LDS (qr_lds_kernel).
+// largest order without a private segment, per case (f32: everything else fits at every order)
+constexpr int NFM_QRL_F32_HESSU_MAX = 15, NFM_QRL_F32_QR_MAX = 16, NFM_QRL_F32_EIGU_MAX = 10, NFM_QRL_F32_EIGUF_MAX = 11, NFM_QRL_F32_RQU_MAX = 11;
+constexpr int NFM_QRL_F64_EIG_MAX = 15, NFM_QRL_F64_EIGF_MAX = 15, NFM_QRL_F64_HESS_MAX = 11, NFM_QRL_F64_HSYM_MAX = 15,
+              NFM_QRL_F64_QR_MAX = 11, NFM_QRL_F64_RQ_MAX = 13, NFM_QRL_F64_EIGU_MAX = 10, NFM_QRL_F64_EIGUF_MAX = 9,
+              NFM_QRL_F64_RQU_MAX = 8;
+constexpr bool qr_large_fits(bool f64, int N, int op)
+{
+    if (N < 9 || N > 16) return false;
+    if (op == QG_HH) return true;
+    if (!f64) {
+        switch (op) {
+        case QG_EIG: case QG_EIG_FAST: case QG_HESS: case QG_HESSSYM: case QG_HESSSYM_U: return true;
+        case QG_HESS_U: return N <= NFM_QRL_F32_HESSU_MAX;
+        case QG_QR: case QG_RQ: return N <= NFM_QRL_F32_QR_MAX;
+        case QG_EIG_U: return N <= NFM_QRL_F32_EIGU_MAX;
+        case QG_EIG_U_FAST: return N <= NFM_QRL_F32_EIGUF_MAX;
+        case QG_RQ_U: return N <= NFM_QRL_F32_RQU_MAX;
+        default: return false;
+        }
+    }
+    switch (op) {
+    case QG_EIG: return N <= NFM_QRL_F64_EIG_MAX;
+    case QG_EIG_FAST: return N <= NFM_QRL_F64_EIGF_MAX;
+    case QG_HESS: case QG_HESS_U: return N <= NFM_QRL_F64_HESS_MAX;
+    case QG_HESSSYM: case QG_HESSSYM_U: return N <= NFM_QRL_F64_HSYM_MAX;
+    case QG_QR: return N <= NFM_QRL_F64_QR_MAX;
+    case QG_RQ: return N <= NFM_QRL_F64_RQ_MAX;
+    case QG_EIG_U: return N <= NFM_QRL_F64_EIGU_MAX;
+    case QG_EIG_U_FAST: return N <= NFM_QRL_F64_EIGUF_MAX;
+    case QG_RQ_U: return N <= NFM_QRL_F64_RQU_MAX;
+    default: return false;
+    }
+}
+#define NFM_QRL_DECL(t, n)                                                                                     \
+    int qr_large_##t##_n##n(int op, const nfm_operand *a, const nfm_operand *b, const nfm_operand *o, int64_t no, \
+                            int64_t ni, const QrParams &p, void *stream);
+#define NFM_QRL_DECL8(t) \
+    NFM_QRL_DECL(t, 9) NFM_QRL_DECL(t, 10) NFM_QRL_DECL(t, 11) NFM_QRL_DECL(t, 12) NFM_QRL_DECL(t, 13) \
+    NFM_QRL_DECL(t, 14) NFM_QRL_DECL(t, 15) NFM_QRL_DECL(t, 16)
+NFM_QRL_DECL8(f32) NFM_QRL_DECL8(f64)
+#undef NFM_QRL_DECL8
+#undef NFM_QRL_DECL
+
+// NFM_EFALLBACK: not a register case (order, operation or layout) -- the caller takes the LDS kernel
+template <typename T>
+static int qr_large_call(int op, const nfm_operand *a, const nfm_operand *b, const nfm_operand *o, int64_t no, int64_t ni,
+                         const QrParams &p, void *stream)
+{
+    if (!qr_large_fits(sizeof(T) == 8, p.n, op)) return NFM_EFALLBACK;
+#define NFM_QRL_CALL(n)                                                                  \
+    case n:                                                                              \
+        return sizeof(T) == 4 ? qr_large_f32_n##n(op, a, b, o, no, ni, p, stream)         \
+                              : qr_large_f64_n##n(op, a, b, o, no, ni, p, stream);
+    switch (p.n) {
+        NFM_QRL_CALL(9) NFM_QRL_CALL(10) NFM_QRL_CALL(11) NFM_QRL_CALL(12) NFM_QRL_CALL(13) NFM_QRL_CALL(14)
+        NFM_QRL_CALL(15) NFM_QRL_CALL(16)
+    default: return NFM_EFALLBACK;
+    }
+#undef NFM_QRL_CALL
+}
+
+#if NFM_QR_PART >= 12 && NFM_QR_PART <= 27
+#define NFM_QRL_F64 ((NFM_QR_PART - 12) / 8)
+#if (NFM_QR_PART - 12) % 8 == 0 // (a literal: it is pasted into the function's name)
+#define NFM_QRL_N 9
+#elif (NFM_QR_PART - 12) % 8 == 1
+#define NFM_QRL_N 10
+#elif (NFM_QR_PART - 12) % 8 == 2
+#define NFM_QRL_N 11
+#elif (NFM_QR_PART - 12) % 8 == 3
+#define NFM_QRL_N 12
+#elif (NFM_QR_PART - 12) % 8 == 4
+#define NFM_QRL_N 13
+#elif (NFM_QR_PART - 12) % 8 == 5
+#define NFM_QRL_N 14
+#elif (NFM_QR_PART - 12) % 8 == 6
+#define NFM_QRL_N 15
+#else
+#define NFM_QRL_N 16
+#endif
+#if NFM_QRL_F64
+using TQl = double;
+#define NFM_QRL_NAME2(n) qr_large_f64_n##n
+#else
+using TQl = float;
+#define NFM_QRL_NAME2(n) qr_large_f32_n##n
+#endif
+#define NFM_QRL_NAME1(n) NFM_QRL_NAME2(n)
+#define NFM_QRL_NAME NFM_QRL_NAME1(NFM_QRL_N)
+int NFM_QRL_NAME(int op, const nfm_operand *a, const nfm_operand *b, const nfm_operand *o, int64_t no, int64_t ni,
+                 const QrParams &p, void *stream)
+{
+    constexpr int N = NFM_QRL_N;
+    constexpr bool F = NFM_QRL_F64 != 0;
+#define NFM_QRL_CASE(OPv, ...)                                                                           \
+    case OPv:                                                                                            \
+        if constexpr (qr_large_fits(F, N, OPv)) return (rec_launch<TQl, __VA_ARGS__, true>(a, b, nullptr, o, no, ni, p, stream)); \
+        break;
+    switch (op) {
+        NFM_QRL_CASE(QG_EIG, EigSymOp<TQl, N, false, false>)
+        NFM_QRL_CASE(QG_EIG_U, EigSymOp<TQl, N, true, false>)
+        NFM_QRL_CASE(QG_EIG_FAST, EigSymOp<TQl, N, false, true>)
+        NFM_QRL_CASE(QG_EIG_U_FAST, EigSymOp<TQl, N, true, true>)
+        NFM_QRL_CASE(QG_HESS, HessOp<TQl, N, false, false>)
+        NFM_QRL_CASE(QG_HESS_U, HessOp<TQl, N, false, true>)
+        NFM_QRL_CASE(QG_HESSSYM, HessOp<TQl, N, true, false>)
+        NFM_QRL_CASE(QG_HESSSYM_U, HessOp<TQl, N, true, true>)
+        NFM_QRL_CASE(QG_QR, QrHessOp<TQl, N>)
+        NFM_QRL_CASE(QG_RQ, RqHessOp<TQl, N, false>)
+        NFM_QRL_CASE(QG_RQ_U, RqHessOp<TQl, N, true>)
+        NFM_QRL_CASE(QG_HH, HouseholderOp<TQl, N>)
+    default: break;
+    }
+#undef NFM_QRL_CASE
+    return NFM_EFALLBACK;
+}
+#endif
+
 template <typename T, int OP>
 static int qr_generic_launch(const nfm_operand *a, const nfm_operand *b, void *out, int64_t out_rec, int64_t no,
                              int64_t ni, const QrParams &p, void *stream)
 {
     constexpr int g = qg_group(OP);
+    {   // orders 9..16 that fit the registers of a lane, contiguous operands (NFM_EFALLBACK otherwise)
+        const nfm_operand o = {out, ni * out_rec, out_rec, 0, 1};
+        const int rc = qr_large_call<T>(OP, a, b, &o, no, ni, p, stream);
+        if (rc != NFM_EFALLBACK) return rc;
+    }
     if constexpr (sizeof(T) == 4) {
         if constexpr (g == 0) return qr_lds_f32_g0(OP, a, b, out, out_rec, no, ni, p, stream);
         else if constexpr (g == 1) return qr_lds_f32_g1(OP, a, b, out, out_rec, no, ni, p, stream);

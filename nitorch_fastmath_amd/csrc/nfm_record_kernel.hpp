@@ -337,8 +337,13 @@ struct KindTile<T, Op, KIND_SOAW> {
     static constexpr int value = (Op::TILE == 256 && RecLayout<T, Op, 512>::gtotal <= NFM_SOAW_LIMIT) ? 512 : Op::TILE;
 };
 
+// NFM_REC_KERNEL_ATTR: extra kernel attributes of a translation unit (the orders 9..16 of the QR family ask for
+// the whole register file: `amdgpu_waves_per_eu(1, 1)`, without which the backend stops at 256 registers and spills)
+#ifndef NFM_REC_KERNEL_ATTR
+#define NFM_REC_KERNEL_ATTR
+#endif
 template <typename T, class Op, int KIND>
-__global__ __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opnd a, Opnd b, Opnd c, Opnd out,
+__global__ NFM_REC_KERNEL_ATTR __launch_bounds__((KindTile<T, Op, KIND>::value)) void rec_kernel(Opnd a, Opnd b, Opnd c, Opnd out,
                                                                           int64_t n_inner,
                                                                           typename Op::Params prm)
 {

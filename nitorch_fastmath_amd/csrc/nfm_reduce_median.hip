@@ -476,7 +476,7 @@ static int lane_pad_any(int red, int omitnan, int64_t rows, const void *x, void 
 {
     constexpr int step = LaneMax<T>::value / kLaneParts; // 16 / 8
     const int dt = sizeof(T) == 4 ? NFM_F32 : NFM_F64;
-    switch ((red - LaneMax<T>::value - 1) / step) {
+    switch ((red - LaneMax<T>::value - 1) / step + LanePadBuckets<T>::first_part) {
     case 0: return lane_part0(dt, -red, omitnan, rows, 1, x, val, idx, stream);
     case 1: return lane_part1(dt, -red, omitnan, rows, 1, x, val, idx, stream);
     case 2: return lane_part2(dt, -red, omitnan, rows, 1, x, val, idx, stream);

@@ -49,9 +49,17 @@ struct LaneMax {
 };
 // rows up to twice that length are sorted by one lane too, padded to one of 8 bucket lengths per dtype
 // (median_lane_pad_kernel): bucket b lives in part b and is reached with red passed NEGATED
+// float32: 129..192 (4 buckets of 16, parts 0..3); float64: 65..96 (4 buckets of 8, parts 4..7).  Longer rows stay
+// on the wavefront-per-row kernel: a 256-key network is 7 700 instructions on more registers than a lane has
+// architectural ones -- a quarter of an hour of compile time per kernel for a few percent over that kernel.
+template <typename T>
+struct LanePadBuckets {
+    static constexpr int value = 4;
+    static constexpr int first_part = sizeof(T) == 4 ? 0 : 4;
+};
 template <typename T>
 struct LanePadMax {
-    static constexpr int value = 2 * LaneMax<T>::value;
+    static constexpr int value = LaneMax<T>::value + LanePadBuckets<T>::value * (LaneMax<T>::value / 8);
 };
 constexpr int kLaneParts = 8; // the lane kernels are compiled in 8 objects: row lengths by their residue mod 8
 

@@ -231,7 +231,7 @@ static int run_lane(int omitnan, int64_t rows, int64_t inner, const void *x, voi
 }
 
 // ---------------------------------------------------------------------------------------------
-// rows of LaneMax+1 .. 2 LaneMax elements (float32: 129..256, float64: 65..128), still ONE ROW PER LANE: the
+// rows of LaneMax+1 .. LanePadMax elements (float32: 129..192, float64: 65..96), still ONE ROW PER LANE: the
 // row is padded to the next BUCKET length (a multiple of 16 / 8 elements: eight buckets per dtype instead of
 // 128 / 64 more instantiations) with keys that sort after everything, the rank is taken among the `red` real
 // ones.  A 2 Ki-element LDS histogram kernel served these lengths before, at 0.5-1.4 TB/s (LDS atomics); the
@@ -259,7 +259,9 @@ __global__ __launch_bounds__(64) void median_lane_pad_kernel(const T *__restrict
     unsigned nan = 0;
 #pragma unroll
     for (int i = 0; i < SURE; i += V) {
-        const VG v = NFM_LDG(reinterpret_cast<const VG *>(own + i));
+        // (plain loads, not the nontemporal ones of the streaming kernels: the eight 16-byte loads a lane makes
+        // to one 128-byte line come from eight instructions, and the line has to stay in the cache between them)
+        const VG v = *reinterpret_cast<const VG *>(own + i);
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             s.at(i + q) = K::of(v[q]);
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64) void median_lane_pad_kernel(const T *__restrict
 #pragma unroll
     for (int i = SURE; i < RED; ++i) {
         if (i < red) { // uniform
-            const T v = NFM_LDG(own + i);
+            const T v = own[i];
             s.at(i) = K::of(v);
             nan += (v != v) ? 1u : 0u;
         } else {
@@ -311,9 +313,14 @@ static int run_lane_pad(int red, int omitnan, int64_t rows, const void *x, void 
 template <typename T>
 static int lane_pad_bucket(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
 {
-    constexpr int RED = LaneMax<T>::value + (NFM_MED_LANE_PART + 1) * PadStep<T>::value;
-    if (red <= RED - PadStep<T>::value || red > RED) return NFM_EINVAL;
-    return run_lane_pad<T, RED>(red, omitnan, rows, x, val, idx, s);
+    constexpr int b = NFM_MED_LANE_PART - LanePadBuckets<T>::first_part; // this part's bucket of dtype T, if any
+    if constexpr (b < 0 || b >= LanePadBuckets<T>::value) {
+        return NFM_EINVAL;
+    } else {
+        constexpr int RED = LaneMax<T>::value + (b + 1) * PadStep<T>::value;
+        if (red <= RED - PadStep<T>::value || red > RED) return NFM_EINVAL;
+        return run_lane_pad<T, RED>(red, omitnan, rows, x, val, idx, s);
+    }
 }
 
 // the lengths of this part, RED = first, first + 8, ... <= LaneMax

@@ -95,19 +95,23 @@ __device__ __forceinline__ double recip(double x)
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
-// 1 / pivot; a zero / non-finite pivot goes through the IEEE division so that singular input
-// yields inf / NaN exactly like a division would
-template <typename T>
-__device__ __forceinline__ T pivot_recip(T pv)
+// 1 / pivot = v_rcp + Newton steps; a zero / infinite / NaN pivot keeps the raw v_rcp (inf / 0 / NaN, what a
+// division gives; the Newton step would turn inf and 0 into NaN).  Branch-free -- a select on the class of the
+// raw reciprocal -- so that the elimination stays ONE basic block and the scheduler can start the pivot search
+// of step k+1 (column k+1 is updated first) under the row updates of step k.  (Round 2 took the IEEE division
+// on a wavefront vote here: a branch per step.)
+__device__ __forceinline__ float pivot_recip(float pv)
 {
-    const T a = fabs_(pv);
-    const bool ok = a > T(1e-30) && a < T(1e30);
-    T r = recip(pv);
-    if (__builtin_expect(__any(!ok), 0)) { // a uniform vote: no exec-mask juggling on the common path
-        const T e = T(1) / pv;
-        r = ok ? r : e;
-    }
-    return r;
+    const float r0 = __builtin_amdgcn_rcpf(pv);
+    const float r = __builtin_fmaf(__builtin_fmaf(-pv, r0, 1.0f), r0, r0);
+    return __builtin_amdgcn_classf(r0, 0x267) ? r0 : r; // NaN (0x3), -inf (0x4), zeros (0x60), +inf (0x200): keep the raw value
+}
+__device__ __forceinline__ double pivot_recip(double pv)
+{
+    const double r0 = __builtin_amdgcn_rcp(pv);
+    double r = __builtin_fma(__builtin_fma(-pv, r0, 1.0), r0, r0);
+    r = __builtin_fma(__builtin_fma(-pv, r, 1.0), r, r);
+    return __builtin_amdgcn_class(r0, 0x267) ? r0 : r;
 }
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }

@@ -98,6 +98,192 @@ static int sym_solve_bcast(int64_t no, int64_t ni, const nfm_operand *mat, const
     return launch_status();
 }
 
+// One matrix (per outer slab) against many vectors at orders 9..16 (`mat` broadcast along the inner batch level:
+// one Hessian, a field of gradients -- `_impl/sym.py:371` broadcasts the batch dims of `mat` and `vec`).
+// The workgroup factors the matrix ONCE -- LU with partial pivoting, element (i, j) in the register of thread
+// 16 i + j, rows and columns of a step exchanged through LDS -- and leaves L, U, 1 / diag(U) and the row
+// permutation in LDS; then every lane streams vectors through them: the permuted right-hand side is fetched
+// component by component (any strides), forward and back substitution run on registers with the factor
+// entries read as LDS broadcasts (one read serves the V vectors of a lane), 16-byte stores when the output
+// records are contiguous.  M^2 multiply-adds per vector against 2 M elements moved: the kernel is a stream
+// over vec / out.  (The LDS-resident fallback this replaces redid the whole elimination per vector.)
+// MATVEC: y = (inp +-) A v with the same streaming part and no factorisation.
+enum { BB_SOLVE = 0, BB_MATVEC = 1 };
+template <typename T, int OP, int V>
+__global__ __launch_bounds__(256) void sym_bcast_big_kernel(Opnd mat, Opnd vec, Opnd inp, Opnd out, int64_t n_inner,
+                                                            int M, int kind, int mode, SolveParams p)
+{
+    constexpr int MX = NFM_MAX_DIM;
+    __shared__ T lu[MX * MX];
+    __shared__ T rdiag[MX];
+    __shared__ int perm[MX];
+    const int tid = threadIdx.x;
+    const int64_t o = blockIdx.y;
+    const T *pm = reinterpret_cast<const T *>(mat.ptr) + o * mat.so;
+    // the full matrix: thread (i, j) = (tid / 16, tid % 16) owns element (i, j)
+    const int ti = tid >> 4, tj = tid & 15;
+    const bool in = ti < M && tj < M;
+    T a = T(0);
+    if (in) {
+        a = kind == NFM_MAT_FULL ? pm[ti * mat.sr + tj * mat.sc] : pm[sym_idx(M, ti, tj) * mat.sc];
+        if (OP == BB_SOLVE && p.has_eps && ti == tj) a += (T)p.eps[ti];
+    }
+    if constexpr (OP == BB_SOLVE) {
+        if (tid < MX) perm[tid] = tid;
+        for (int k = 0; k < M; ++k) {
+            lu[ti * MX + tj] = a;
+            __syncthreads();
+            // pivot: first row >= k with the largest |a_rk| (every thread finds it for itself: broadcast reads)
+            int pr = k;
+            T best = fabs_(lu[k * MX + k]);
+            for (int r = k + 1; r < M; ++r) {
+                const T x = fabs_(lu[r * MX + k]);
+                if (x > best) { best = x; pr = r; }
+            }
+            // rows k and pr change places
+            if (ti == k) a = lu[pr * MX + tj];
+            else if (ti == pr) a = lu[k * MX + tj];
+            if (tid == 0 && pr != k) { const int t = perm[k]; perm[k] = perm[pr]; perm[pr] = t; }
+            const T piv = lu[pr * MX + k];               // a'[k][k]
+            const T akj = lu[pr * MX + tj];              // a'[k][j]
+            T aik = lu[ti * MX + k];                     // a'[i][k] for i > k: row i is unchanged unless i == pr
+            if (ti == pr) aik = lu[k * MX + k];
+            __syncthreads();
+            if (in && ti > k) {
+                const T l = aik / piv;
+                if (tj == k) a = l;
+                else if (tj > k) a = a - l * akj;
+            }
+        }
+        lu[ti * MX + tj] = a;
+        __syncthreads();
+        if (tid < M) rdiag[tid] = T(1) / lu[tid * MX + tid];
+    } else {
+        lu[ti * MX + tj] = a;
+    }
+    __syncthreads();
+
+    const T *pv0 = reinterpret_cast<const T *>(vec.ptr) + o * vec.so;
+    const T *pi0 = inp.ptr ? reinterpret_cast<const T *>(inp.ptr) + o * inp.so : nullptr;
+    T *po0 = reinterpret_cast<T *>(out.ptr) + o * out.so;
+    const bool vstore = out.sc == 1 && out.si % (16 / (int)sizeof(T)) == 0 && (reinterpret_cast<uintptr_t>(po0) & 15) == 0;
+    for (int64_t tile = blockIdx.x; tile * (256 * V) < n_inner; tile += gridDim.x) {
+        // the factors are re-read from LDS in every tile (broadcast reads, cheap): hoisted out of this loop, the 256
+        // entries would take the whole register file and leave one wavefront per SIMD to a streaming kernel
+        asm volatile("" ::: "memory");
+        const int64_t base = tile * (256 * V) + tid;
+        T x[V][MX];
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int64_t n = base + q * 256;
+            const T *pv = pv0 + (n < n_inner ? n : n_inner - 1) * vec.si;
+#pragma unroll
+            for (int i = 0; i < MX; ++i)
+                if (i < M) x[q][i] = pv[(OP == BB_SOLVE ? perm[i] : i) * vec.sc]; // P v: the permuted fetch
+        }
+        if constexpr (OP == BB_SOLVE) {
+            // L y = P v (unit lower), then U x = y
+#pragma unroll
+            for (int i = 1; i < MX; ++i)
+                if (i < M) {
+#pragma unroll
+                    for (int j = 0; j < i; ++j) {
+                        const T l = lu[i * MX + j];
+#pragma unroll
+                        for (int q = 0; q < V; ++q) x[q][i] = fma_(-l, x[q][j], x[q][i]);
+                    }
+                }
+#pragma unroll
+            for (int i = MX - 1; i >= 0; --i)
+                if (i < M) {
+#pragma unroll
+                    for (int j = i + 1; j < MX; ++j)
+                        if (j < M) {
+                            const T u = lu[i * MX + j];
+#pragma unroll
+                            for (int q = 0; q < V; ++q) x[q][i] = fma_(-u, x[q][j], x[q][i]);
+                        }
+                    const T r = rdiag[i];
+#pragma unroll
+                    for (int q = 0; q < V; ++q) x[q][i] *= r;
+                }
+        } else {
+            T y[V][MX];
+#pragma unroll
+            for (int i = 0; i < MX; ++i)
+                if (i < M) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) y[q][i] = T(0);
+#pragma unroll
+                    for (int j = 0; j < MX; ++j)
+                        if (j < M) {
+                            const T aij = lu[i * MX + j];
+#pragma unroll
+                            for (int q = 0; q < V; ++q) y[q][i] = fma_(aij, x[q][j], y[q][i]);
+                        }
+                }
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const int64_t n = base + q * 256;
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < M) {
+                        T r = y[q][i];
+                        if (mode != 0) {
+                            const T b = pi0[(n < n_inner ? n : n_inner - 1) * inp.si + i * inp.sc];
+                            r = mode > 0 ? b + r : b - r;
+                        }
+                        x[q][i] = r;
+                    }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int64_t n = base + q * 256;
+            if (n >= n_inner) continue;
+            T *po = po0 + n * out.si;
+            if (vstore) {
+                using VG = typename VecOf<T>::type;
+                constexpr int NV = VecOf<T>::N;
+#pragma unroll
+                for (int i = 0; i < MX; i += NV)
+                    if (i < M) {
+                        if (i + NV <= M) {
+                            VG v;
+#pragma unroll
+                            for (int c = 0; c < NV; ++c) v[c] = x[q][i + c];
+                            *reinterpret_cast<VG *>(po + i) = v;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < NV; ++c)
+                                if (i + c < M) po[i + c] = x[q][i + c];
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < M) po[i * out.sc] = x[q][i];
+            }
+        }
+    }
+}
+
+template <typename T, int OP>
+static int sym_bcast_big(int M, int kind, int mode, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
+                         const nfm_operand *inp, const nfm_operand *out, const SolveParams &p, void *stream)
+{
+    constexpr int V = sizeof(T) == 4 ? 4 : 2;
+    int64_t nblk = (ni + 256 * V - 1) / (256 * V);
+    const int64_t cap = (2048 + no - 1) / no; // the factorisation is paid once per workgroup: a few per CU, each streams many tiles
+    if (nblk > cap) nblk = cap;
+    if (no > 65535) return NFM_ESIZE;
+    nfm_operand none = {nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL((sym_bcast_big_kernel<T, OP, V>), dim3((unsigned)nblk, (unsigned)no, 1), dim3(256, 1, 1), 0,
+                       static_cast<hipStream_t>(stream), make_opnd(mat, MODE_STRIDED), make_opnd(vec, MODE_STRIDED),
+                       make_opnd(inp ? inp : &none, MODE_STRIDED), make_opnd(out, MODE_STRIDED), ni, M, kind, mode, p);
+    return launch_status();
+}
+
 template <typename T>
 static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
                        const nfm_operand *out, const SolveParams &p, void *stream)
@@ -114,6 +300,8 @@ static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operan
         default: return sym_solve_bcast<T, 8>(no, ni, mat, vec, out, p, stream);
         }
     }
+    if (M > 8 && (kind == NFM_MAT_SYM || kind == NFM_MAT_FULL) && mat->stride_inner == 0 && ni >= 1024)
+        return sym_bcast_big<T, BB_SOLVE>(M, kind, 0, no, ni, mat, vec, nullptr, out, p, stream);
     if (M > 8) {
         if (kind == NFM_MAT_SYM && no == 1) { // contiguous operands: registers; else LDS-resident
             if (rowwave_first<T>(M, RWW_SOLVE)) { // one matrix per 16 lanes (nfm_rowwave.hip)
@@ -148,6 +336,10 @@ template <typename T>
 static int sym_matvec_t(int M, int kind, int mode, int64_t no, int64_t ni, const nfm_operand *mat,
                         const nfm_operand *vec, const nfm_operand *inp, const nfm_operand *out, void *stream)
 {
+    if (M > 8 && (kind == NFM_MAT_SYM || kind == NFM_MAT_FULL) && mat->stride_inner == 0 && ni >= 1024) {
+        SolveParams sp{};
+        return sym_bcast_big<T, BB_MATVEC>(M, kind, mode, no, ni, mat, vec, inp, out, sp, stream);
+    }
     if (M > 8) {
         if (kind == NFM_MAT_SYM && no == 1) {
             const int rc = Large<T>::sym_matvec(M, mode, ni, mat, vec, inp, out, stream);

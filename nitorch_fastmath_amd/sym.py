@@ -124,11 +124,26 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
     return out
 
 
+def _cast(dtype, *tensors):
+    """differentiable torch route of the orders > MAX_DIM: operands as tensors of the computation dtype"""
+    ts = [None if t is None else torch.as_tensor(t) for t in tensors]
+    if dtype is None:
+        dtype = ts[0].dtype
+        for t in ts[1:]:
+            if t is not None:
+                dtype = torch.promote_types(dtype, t.dtype)
+    return [None if t is None else t.to(dtype) for t in ts]
+
+
 def _matvec(mode, inp, mat, vec, dtype, out):
     from ._autograd import SymMatvecFn, needs_grad
     if needs_grad(inp, mat, vec):
         if out is not None:
             raise RuntimeError('out= is not supported for tensors that require grad')
+        if torch.as_tensor(vec).shape[-1] > _lib.MAX_DIM:   # torch.linalg route: torch differentiates it (forward AND backward)
+            from . import _bigorder
+            mat_, vec_, inp_ = _cast(dtype, mat, vec, inp)
+            return _bigorder.sym_matvec(mode, inp_, mat_, vec_, None, mat_.shape[-1])
         return SymMatvecFn.apply(mode, inp, torch.as_tensor(mat), torch.as_tensor(vec), dtype)
     return _matvec_impl(mode, inp, mat, vec, dtype, out)
 
@@ -206,6 +221,10 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     if needs_grad(mat, vec):
         if out is not None:
             raise RuntimeError('out= is not supported for tensors that require grad')
+        if torch.as_tensor(vec).shape[-1] > _lib.MAX_DIM:   # torch.linalg route: torch differentiates it
+            from . import _bigorder
+            mat_, vec_ = _cast(dtype, mat, vec)
+            return _bigorder.sym_solve(mat_, vec_, eps, None, mat_.shape[-1])
         return SymSolveFn.apply(torch.as_tensor(mat), torch.as_tensor(vec), eps, dtype)
     dev, dtype, (mat, vec) = _prep(dtype, mat, vec)
     N = vec.shape[-1]
@@ -256,6 +275,10 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
     if needs_grad(mat):
         if out is not None:
             raise RuntimeError('out= is not supported for tensors that require grad')
+        if _nb_prm(torch.as_tensor(mat).shape[-1]) > _lib.MAX_DIM:
+            from . import _bigorder
+            (mat_,) = _cast(dtype, mat)
+            return _bigorder.sym_invert(mat_, _nb_prm(mat_.shape[-1]), bool(diag), None)
         return SymInvertFn.apply(torch.as_tensor(mat), bool(diag), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])
@@ -289,6 +312,10 @@ def sym_det(mat, dtype=None, out=None):
     if needs_grad(mat):
         if out is not None:
             raise RuntimeError('out= is not supported for tensors that require grad')
+        if _nb_prm(torch.as_tensor(mat).shape[-1]) > _lib.MAX_DIM:
+            from . import _bigorder
+            (mat_,) = _cast(dtype, mat)
+            return _bigorder.sym_det(mat_, _nb_prm(mat_.shape[-1]), None)
         return SymDetFn.apply(torch.as_tensor(mat), dtype)
     dev, dtype, (mat,) = _prep(dtype, mat)
     M = _nb_prm(mat.shape[-1])

@@ -18,9 +18,9 @@ def timeit(fn, reps=8):
 
 print('| layout | M | n | ms | solves/s | algorithmic GB/s |')
 print('|---|---|---|---|---|---|')
-for M in (4, 6):
+for M in (4, 6, 12, 16):
     K = M * (M + 1) // 2
-    n = 17_000_000          # not a power of two: component planes 2^k bytes apart camp on one HBM channel
+    n = 17_000_000 if M <= 8 else 4_250_000   # not a power of two: component planes 2^k bytes apart camp on one HBM channel
     g = torch.Generator(device=dev).manual_seed(M)
     mat = 0.3 * torch.randn(n, K, device=dev, generator=g) / M
     mat[:, :M] += 2
@@ -39,8 +39,8 @@ for M in (4, 6):
     big = torch.randn(n // 2, K, 2, device=dev, generator=g)
     big[:, :M, 0] += 4
     cases.append(('component stride 2', big[..., 0], vec[:n // 2], (K + 2 * M) * 4))
-    m3 = mat.view(4000, 4250, K)[:, ::2]
-    v3 = vec.view(4000, 4250, M)[:, ::2]
+    m3 = mat.view(n // 4250, 4250, K)[:, ::2]
+    v3 = vec.view(n // 4250, 4250, M)[:, ::2]
     cases.append(('two-level batch (rows of a strided 2-D field)', m3, v3, (K + 2 * M) * 4))
     pad = torch.zeros(n // 2, K + 2, device=dev)
     pad[:, :K] = mat[:n // 2]

@@ -166,3 +166,73 @@ def test_orders_above_16_take_the_references_route_on_device(dev, dn):
     a = t(f64.astype(dtype), dev)
     assert relerr(B.batchinv(a).cpu().numpy(), np.linalg.inv(f64)) <= tol
     assert relerr(B.batchdet(a).cpu().numpy(), np.linalg.det(f64)) <= 10 * tol
+
+
+def test_orders_above_16_backward(dev):
+    """orders > 16 with requires_grad: forward AND backward go through torch.linalg on the device (the custom
+    autograd Functions end in kernels capped at order 16: round 2 raised only at `.backward()`); gradients
+    against the dense formulas"""
+    M, n = 20, 6
+    mat_np, vec_np = spd_np(n, M, np.float64, 11)
+    S = N().sym
+    mat = t(mat_np, dev).requires_grad_(True)
+    vec = t(vec_np, dev).requires_grad_(True)
+    x = S.sym_solve(mat, vec)
+    (x * x).sum().backward()
+    assert mat.grad is not None and vec.grad is not None and mat.grad.shape == mat.shape
+    # d/dv sum(x^2) = 2 A^-1 x
+    full = S.sym_to_full(mat.detach())
+    want_v = 2 * torch.linalg.solve(full, x.detach().unsqueeze(-1)).squeeze(-1)
+    assert relerr(vec.grad.cpu().numpy(), want_v.cpu().numpy()) <= 1e-10
+    for fn in (lambda m: S.sym_invert(m).sum(), lambda m: S.sym_det(m).sum(), lambda m: S.sym_matvec(m, vec.detach()).sum(),
+               lambda m: S.sym_invert(m, diag=True).sum()):
+        m2 = t(mat_np, dev).requires_grad_(True)
+        fn(m2).backward()
+        assert m2.grad is not None and torch.isfinite(m2.grad).all() and m2.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [9, 12, 13, 16])
+def test_one_matrix_many_vectors_large_orders(dev, oracle, dn, M):
+    """`mat` broadcast against a batch of vectors at orders 9..16 (`_impl/sym.py:371`: one Hessian, a field of
+    gradients): the workgroup factors the matrix once and streams the vectors (sym_bcast_big_kernel) --
+    sym_solve (with eps, full-matrix storage, strided / channel-first vectors, several slabs), sym_matvec /
+    addmatvec / submatvec; against the oracle on the expanded operands"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    n = 4096 + 517
+    mat, vec = spd_np(n, M, dtype, 1900 + M)
+    one = mat[:1]                                           # (1, K)
+    S = N().sym
+    md, vd = t(one, dev), t(vec, dev)
+    rep = np.broadcast_to(one, (n, one.shape[-1]))
+    got = S.sym_solve(md, vd).cpu().numpy()
+    assert got.shape == (n, M) and relerr(got, oracle.sym_solve(rep, vec)) <= TOL[dn]
+    # the same call on materialised operands takes the per-record kernels: the two agree to the same bar
+    assert relerr(got, S.sym_solve(t(rep.copy(), dev), vd).cpu().numpy()) <= TOL[dn]
+    # eps, out=, channel-first vectors / outputs
+    eps = [0.5] * M
+    ref_eps = oracle.sym_solve(rep + np.concatenate([np.full(M, 0.5), np.zeros(one.shape[-1] - M)]).astype(dtype), vec)
+    assert relerr(S.sym_solve(md, vd, eps=eps).cpu().numpy(), ref_eps) <= TOL[dn]
+    vcf = vd.t().contiguous().t()
+    ocf = torch.empty(M, n, dtype=vd.dtype, device=dev).t()
+    S.sym_solve(md, vcf, out=ocf)
+    assert relerr(ocf.cpu().numpy(), oracle.sym_solve(rep, vec)) <= TOL[dn]
+    # full-matrix storage (NN = M^2) broadcast
+    full = S.sym_to_full(md)                                # (1, M, M)
+    assert relerr(S.sym_solve(full.reshape(1, M * M), vd).cpu().numpy(), oracle.sym_solve(rep, vec)) <= TOL[dn]
+    # several slabs: (B, 1, K) against (B, n, M)
+    B = 3
+    mats, vecs = spd_np(B, M, dtype, 7)[0], vec[: B * 1500].reshape(B, 1500, M)
+    gs = S.sym_solve(t(mats[:, None], dev), t(vecs, dev)).cpu().numpy()
+    for b in range(B):
+        assert relerr(gs[b], oracle.sym_solve(np.broadcast_to(mats[b], (1500, mats.shape[-1])), vecs[b])) <= TOL[dn]
+    # matvec family: reference fma chains per row -> agreement to rounding of an M-term sum
+    mv = oracle.sym_matvec(rep, vec)
+    tolmv = 4 * M * EPS[dn]
+    assert relerr(S.sym_matvec(md, vd).cpu().numpy(), mv) <= tolmv
+    inp = np.random.default_rng(5).standard_normal((n, M)).astype(dtype)
+    assert relerr(S.sym_addmatvec(t(inp, dev), md, vd).cpu().numpy(), inp + mv) <= tolmv
+    assert relerr(S.sym_submatvec(t(inp, dev), md, vd).cpu().numpy(), inp - mv) <= tolmv
+    # singular matrix: inf / nan like a division, no hang
+    z = torch.zeros(1, one.shape[-1], dtype=vd.dtype, device=dev)
+    assert not torch.isfinite(S.sym_solve(z, vd)).any()

@@ -112,3 +112,29 @@ def test_qr_functions_capture_with_check_finite_off(dev):
     with pytest.raises(Exception):
         graphed(lambda x: N().eig_sym(x), a)        # the host read inside a capture is an error
     torch.cuda.synchronize()
+
+
+def test_fast_accessors_agree_with_the_public_api(dev):
+    """the facade reads the current stream and device through private torch accessors (cheaper per call);
+    they must mean what the public API means: inside a non-default stream context, and `on_device` must
+    leave the current device as it found it"""
+    from nitorch_fastmath_amd import _dispatch as D
+    assert D.stream_ptr(dev) == torch.cuda.current_stream(dev).cuda_stream
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        assert D.stream_ptr(dev) == side.cuda_stream == torch.cuda.current_stream(dev).cuda_stream
+    assert D.stream_ptr(dev) == torch.cuda.current_stream(dev).cuda_stream
+    before = torch.cuda.current_device()
+    with D.on_device(dev):
+        assert torch.cuda.current_device() == dev.index
+    assert torch.cuda.current_device() == before
+    # a broken private accessor falls back to the public API instead of raising
+    saved = D._raw_stream, D._cur_device
+    try:
+        D._raw_stream = lambda *a: (_ for _ in ()).throw(TypeError('signature changed'))
+        D._cur_device = lambda *a: (_ for _ in ()).throw(TypeError('signature changed'))
+        assert D.stream_ptr(dev) == torch.cuda.current_stream(dev).cuda_stream
+        with D.on_device(dev):
+            assert torch.cuda.current_device() == dev.index
+    finally:
+        D._raw_stream, D._cur_device = saved
