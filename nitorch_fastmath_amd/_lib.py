@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('NFM_HIP_LIB') or os.path.join(_HERE, 'libnfm_hip.so')   # override: kernel experiments
+# (kernel experiments load another build of the library: honoured only under NFM_DEBUG, the one variable the
+# product reads; the row-wave measurement knobs of nfm_rowwave.hip sit behind the same gate)
+LIB_PATH = (os.environ.get('NFM_HIP_LIB') if os.environ.get('NFM_DEBUG') else None) or os.path.join(_HERE, 'libnfm_hip.so')
 
 F32, F64 = 0, 1
 MAT_SYM, MAT_DIAG, MAT_SCAL, MAT_FULL = 0, 1, 2, 3

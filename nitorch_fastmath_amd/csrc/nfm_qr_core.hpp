@@ -692,6 +692,29 @@ __device__ __forceinline__ void band_sweep_cr1(T (&d)[Dim<NT>::MAX], T (&l)[Dim<
                 if (k + 2 < m) rot_pair1(u2[k], u1[k + 1], lc[k], ls[k]); // column k+2: (a[k][k+2], a[k+1][k+2])
         }
     }
+    // U <- U Q: rotation k combines columns k, k+1.  float64: column k+1 is carried in registers from one rotation
+    // to the next (uc), so that a U kept in LDS is read and written once per column and sweep instead of twice (for
+    // a U in registers this is the same code as rotating in place).  float32 rotates in place: measured, the
+    // carried form of the packed rotation was 1.7x SLOWER on the LDS-resident orders (profiles/r03/qr_large_table.md).
+    if constexpr (WITH_U && sizeof(T) == 4) {
+#pragma unroll
+        for (int k = 0; k < MX - 1; ++k) {
+            if (k < m - 1) {
+                if (k >= 1) rot_pair1(u1[k - 1 < 0 ? 0 : k - 1], u2[k - 1 < 0 ? 0 : k - 1], lc[k], ls[k]); // row k-1
+                rot_pair1(d[k], u1[k], lc[k], ls[k]);         // row k:   (a[k][k],   a[k][k+1])
+                rot_pair1(l[k], d[k + 1], lc[k], ls[k]);      // row k+1: (a[k+1][k], a[k+1][k+1])
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < n) rot_pair1(u[i][k], u[i][k + 1], lc[k], ls[k]);
+            }
+        }
+        return;
+    }
+    T uc[MX];
+    if (WITH_U) {
+#pragma unroll
+        for (int i = 0; i < MX; ++i) uc[i] = (i < n) ? u[i][0] : T(0);
+    }
 #pragma unroll
     for (int k = 0; k < MX - 1; ++k) {
         if (k < m - 1) {
@@ -699,11 +722,23 @@ __device__ __forceinline__ void band_sweep_cr1(T (&d)[Dim<NT>::MAX], T (&l)[Dim<
             rot_pair1(d[k], u1[k], lc[k], ls[k]);         // row k:   (a[k][k],   a[k][k+1])
             rot_pair1(l[k], d[k + 1], lc[k], ls[k]);      // row k+1: (a[k+1][k], a[k+1][k+1])
             if (WITH_U) {
+                T un[MX];
+#pragma unroll
+                for (int i = 0; i < MX; ++i) un[i] = (i < n) ? u[i][k + 1] : T(0);
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
-                    if (i < n) rot_pair1(u[i][k], u[i][k + 1], lc[k], ls[k]);
+                    if (i < n) {
+                        rot_pair1(uc[i], un[i], lc[k], ls[k]);
+                        u[i][k] = uc[i];
+                        uc[i] = un[i];
+                    }
             }
         }
+    }
+    if (WITH_U) { // the last column the sweep touched
+#pragma unroll
+        for (int i = 0; i < MX; ++i)
+            if (i < n) u[i][m - 1] = uc[i];
     }
 }
 
@@ -817,6 +852,11 @@ __device__ __forceinline__ void tri_sweep_fast1(T (&d)[Dim<NT>::MAX], T (&e)[Dim
     constexpr int MX = Dim<NT>::MAX;
     T p = d[0] - sigma, q = e[0];
     T cprev = T(1), sprev = T(0);
+    T uc[MX]; // column k of U, carried from one rotation to the next (band_sweep_cr1)
+    if (WITH_U) {
+#pragma unroll
+        for (int i = 0; i < MX; ++i) uc[i] = (i < n) ? u[i][0] : T(0);
+    }
 #pragma unroll
     for (int k = 0; k < MX - 1; ++k) {
         if (k < m - 1) {
@@ -834,15 +874,27 @@ __device__ __forceinline__ void tri_sweep_fast1(T (&d)[Dim<NT>::MAX], T (&e)[Dim
             d[k] = fma_t(c * cprev, r, S * uk) + sigma;
             if (k > 0) e[k - 1 < 0 ? 0 : k - 1] = sprev * r;
             if (WITH_U) {
+                T un[MX];
+#pragma unroll
+                for (int i = 0; i < MX; ++i) un[i] = (i < n) ? u[i][k + 1] : T(0);
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
-                    if (i < n) rot_fast1(u[i][k], u[i][k + 1], c, sr);
+                    if (i < n) {
+                        rot_fast1(uc[i], un[i], c, sr);
+                        u[i][k] = uc[i];
+                        uc[i] = un[i];
+                    }
             }
             p = pn;
             q = qn;
             cprev = c;
             sprev = S;
         }
+    }
+    if (WITH_U) {
+#pragma unroll
+        for (int i = 0; i < MX; ++i)
+            if (i < n) u[i][m - 1] = uc[i];
     }
     d[m - 1] = fma_t(cprev, p, sigma);
     e[m - 2] = sprev * p;
@@ -943,31 +995,38 @@ __device__ __forceinline__ void reflect_left1(MA &a, int n, int k0, const T (&w)
 {
 #pragma clang fp contract(off)
     constexpr int MX = Dim<NT>::MAX;
+    // (every column is read ONCE into `col`, updated and written back: a matrix kept in LDS is not read twice)
     if constexpr (FAST) { // eig_sym's fast arithmetic: the same update contracted to fma
 #pragma unroll
         for (int c = 0; c < MX; ++c)
             if (c < n) {
+                T col[MX];
+#pragma unroll
+                for (int r = 0; r < MX; ++r) col[r] = (r >= k0 && r < n) ? a[r][c] : T(0);
                 T d = T(0);
 #pragma unroll
                 for (int r = 0; r < MX; ++r)
-                    if (r >= k0 && r < n) d = fma_t(w[r - k0 < 0 ? 0 : r - k0], a[r][c], d);
+                    if (r >= k0 && r < n) d = fma_t(w[r - k0 < 0 ? 0 : r - k0], col[r], d);
                 d += d;
 #pragma unroll
                 for (int r = 0; r < MX; ++r)
-                    if (r >= k0 && r < n) a[r][c] = fma_t(-w[r - k0 < 0 ? 0 : r - k0], d, a[r][c]);
+                    if (r >= k0 && r < n) a[r][c] = fma_t(-w[r - k0 < 0 ? 0 : r - k0], d, col[r]);
             }
         return;
     }
 #pragma unroll
     for (int c = 0; c < MX; ++c)
         if (c < n) {
+            T col[MX];
+#pragma unroll
+            for (int r = 0; r < MX; ++r) col[r] = (r >= k0 && r < n) ? a[r][c] : T(0);
             T d = T(0);
 #pragma unroll
             for (int r = 0; r < MX; ++r)
-                if (r >= k0 && r < n) d += w[r - k0 < 0 ? 0 : r - k0] * a[r][c];
+                if (r >= k0 && r < n) d += w[r - k0 < 0 ? 0 : r - k0] * col[r];
 #pragma unroll
             for (int r = 0; r < MX; ++r)
-                if (r >= k0 && r < n) a[r][c] -= T(2) * (w[r - k0 < 0 ? 0 : r - k0] * d);
+                if (r >= k0 && r < n) a[r][c] = col[r] - T(2) * (w[r - k0 < 0 ? 0 : r - k0] * d);
         }
 }
 

@@ -476,6 +476,9 @@ static int lane_pad_any(int red, int omitnan, int64_t rows, const void *x, void 
 {
     constexpr int step = LaneMax<T>::value / kLaneParts; // 16 / 8
     const int dt = sizeof(T) == 4 ? NFM_F32 : NFM_F64;
+    if (red > LanePadMax<T>::value) // two lanes per row: part 5 (float32) / part 1 (float64)
+        return sizeof(T) == 4 ? lane_part5(dt, -red, omitnan, rows, 1, x, val, idx, stream)
+                              : lane_part1(dt, -red, omitnan, rows, 1, x, val, idx, stream);
     switch ((red - LaneMax<T>::value - 1) / step + LanePadBuckets<T>::first_part) {
     case 0: return lane_part0(dt, -red, omitnan, rows, 1, x, val, idx, stream);
     case 1: return lane_part1(dt, -red, omitnan, rows, 1, x, val, idx, stream);
@@ -495,7 +498,7 @@ static int run(int omitnan, int64_t rows, int64_t red, const void *x, void *ws, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (red >= 2 && red <= LaneMax<T>::value && rows >= kLaneMinRows && reinterpret_cast<uintptr_t>(x) % sizeof(T) == 0)
         return lane_any(sizeof(T) == 4 ? NFM_F32 : NFM_F64, (int)red, omitnan, rows, 1, x, val, idx, stream);
-    if (red > LaneMax<T>::value && red <= LanePadMax<T>::value && rows >= kLanePadMinRows &&
+    if (red > LaneMax<T>::value && red <= 2 * LaneMax<T>::value && rows >= kLanePadMinRows &&
         reinterpret_cast<uintptr_t>(x) % sizeof(T) == 0)
         return lane_pad_any<T>((int)red, omitnan, rows, x, val, idx, stream);
     if (red <= 32) {

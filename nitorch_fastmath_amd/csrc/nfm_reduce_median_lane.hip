@@ -323,6 +323,138 @@ static int lane_pad_bucket(int red, int omitnan, int64_t rows, const void *x, vo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// rows of LanePadMax+1 .. 2 LaneMax elements (float32: 193..256, float64: 97..128): TWO LANES PER ROW.  Each lane
+// of a pair sorts one half of the row (H = LaneMax keys, the network the exact-length kernels use), then the two
+// sorted halves A, B are combined without a merge: the H smallest keys of their union are
+// { min(A[i], B[H-1-i]) : i < H } (the first half of a bitonic split), so the key of rank H-1 of the 2 H slots is
+// max_i min(A[i], B[H-1-i]) -- H v_min with the partner's register through DPP (quad_perm [1,0,3,2]) and H-1 v_max.
+// The rank wanted, k = (count-1)/2 of `count` real keys, is MADE to be H-1: the 2 H - count slots that hold no real
+// key (padding, omitted NaNs) are filled with H-1-k smallest keys (0: never a real key) and largest keys (~0) for
+// the rest; k + (H-1-k) = H-1.  With no NaN in the wavefront the split is the same for every row and is decided
+// per slot index; rows with omitted NaNs turn that many more of their NaN keys into smallest keys (a vote, a
+// sequential pass).  ~27 compare-exchange instructions per key against ~30 for one lane sorting 2 H keys, on half
+// the registers (three wavefronts per SIMD instead of one) and at the compile time of the H-key network.
+__device__ __forceinline__ unsigned pair_swap32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+}
+template <typename U>
+__device__ __forceinline__ U pair_swap(U v)
+{
+    if constexpr (sizeof(U) == 4) {
+        return (U)pair_swap32((unsigned)v);
+    } else {
+        const unsigned lo = pair_swap32((unsigned)v), hi = pair_swap32((unsigned)((unsigned long long)v >> 32));
+        return (U)(((unsigned long long)hi << 32) | lo);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void median_lane_pair_kernel(const T *__restrict__ x, int64_t rows, int red, int omitnan,
+                                                              T *__restrict__ val, int64_t *__restrict__ idx)
+{
+    using K = Key<T>;
+    using U = typename K::U;
+    using VG = typename VecOf<T>::gtype;
+    constexpr int V = VecOf<T>::N;
+    constexpr int H = LaneMax<T>::value;  // key slots per lane
+    const int h = threadIdx.x & 1;
+    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 1);
+    const bool live = row < rows;
+    // the row is split in the middle: lane 0 of the pair takes the first mine0 = ceil(red / 2) elements, lane 1 the
+    // other floor(red / 2) (3 H / 4 < mine <= H each), so both fetch with the same 16-byte loads up to `vend` and
+    // at most V + 1 single elements after it; their remaining slots are padding
+    const int mine0 = (red + 1) / 2, mine1 = red / 2;
+    const int mine = h ? mine1 : mine0;
+    const int vend = (mine1 / V) * V;  // uniform
+    const T *own = x + (live ? row : rows - 1) * (int64_t)red + h * mine0;
+    // padding: 2 H - red slots, pads0 of them in lane 0; the first lo0 = H-1 - (red-1)/2 of them (lane 0's first) hold
+    // the smallest key, the others the largest: the split of a row without omitted NaNs (the same for every row)
+    const int lo0 = (H - 1) - (red - 1) / 2;
+    const int pads0 = H - mine0;
+    const int z0 = lo0 < pads0 ? lo0 : pads0;
+    const int zmine = h ? lo0 - z0 : z0; // smallest-key slots among this lane's padding (its first zmine padding slots)
+    Keys<U, H> s;
+    unsigned nan = 0;
+#pragma unroll
+    for (int i = 0; i < H; i += V) {
+        if (i < vend) { // uniform
+            const VG v = *reinterpret_cast<const VG *>(own + i); // plain loads: a lane walks its cache lines with consecutive loads
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                s.at(i + q) = K::of(v[q]);
+                nan += (v[q] != v[q]) ? 1u : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const int e = i + q;
+                U key = (e - mine < zmine) ? U(0) : ~U(0); // padding slot number e - mine of this lane
+                if (e < mine0) { // uniform: at most V + 1 elements past vend are real in either lane
+                    const bool real = e < mine;
+                    const T v = own[real ? e : mine - 1];
+                    key = real ? K::of(v) : key;
+                    nan += (real && v != v) ? 1u : 0u;
+                }
+                s.at(e) = key;
+            }
+        }
+        if (i % 32 == 32 - V) __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned nan_row = nan + pair_swap(nan);
+    const unsigned count = omitnan ? (unsigned)red - nan_row : (unsigned)red;
+    const bool want_nan = (!omitnan && nan_row > 0) || count == 0;
+    if (__builtin_expect(__any(omitnan && nan_row > 0 && count > 0), 0)) {
+        // omitted NaNs lower the rank: k = (count-1)/2, so (red-1)/2 - k more smallest keys are needed; they are
+        // made out of this row's NaN keys, the first lane of the pair first
+        const int more = (omitnan && count > 0) ? (int)((unsigned)(red - 1) / 2 - (count - 1) / 2) : 0;
+        const int nan0 = (int)(h ? nan_row - nan : nan);
+        const int take0 = more < nan0 ? more : nan0; // lane 0's share
+        int budget = h ? more - take0 : take0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const bool real_nan = i < mine && s.at(i) == ~U(0);
+            const bool turn = real_nan && budget > 0;
+            s.at(i) = turn ? U(0) : s.at(i);
+            budget -= turn ? 1 : 0;
+        }
+    }
+    sort_network<U, H>(s);
+    // rank H-1 of the pair's 2 H slots
+    U chosen = U(0);
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const U other = pair_swap(s.at(H - 1 - i));
+        const U m = s.at(i) < other ? s.at(i) : other;
+        chosen = m > chosen ? m : chosen;
+    }
+    if (want_nan) chosen = ~U(0);
+    if (live) {
+        int first = 0x7fffffff;
+        if (idx != nullptr) { // uniform: first position holding the chosen key (a NaN result: the first NaN)
+            for (int i = mine - 1; i >= 0; --i) first = (K::of(own[i]) == chosen) ? h * mine0 + i : first;
+            const int of = (int)pair_swap((unsigned)first);
+            first = of < first ? of : first;
+        }
+        if (h == 0) {
+            val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
+            if (idx != nullptr) idx[row] = first;
+        }
+    }
+}
+
+template <typename T>
+static int run_lane_pair(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
+{
+    if (red <= LanePadMax<T>::value || red > 2 * LaneMax<T>::value) return NFM_EINVAL;
+    const int64_t nblk = (rows + 31) / 32;
+    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    hipLaunchKernelGGL((median_lane_pair_kernel<T>), dim3((unsigned)nblk), dim3(64), 0, s, static_cast<const T *>(x), rows,
+                       red, omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx));
+    return launch_status();
+}
+
 // the lengths of this part, RED = first, first + 8, ... <= LaneMax
 template <typename T, int RED>
 static int lane_chain(int red, int omitnan, int64_t rows, int64_t inner, const void *x, void *val, void *idx,
@@ -344,6 +476,18 @@ int NFM_MED_CAT(lane_part, NFM_MED_LANE_PART)(int dtype, int red, int omitnan, i
     constexpr int first = NFM_MED_LANE_PART >= 2 ? NFM_MED_LANE_PART : NFM_MED_LANE_PART + kLaneParts; // lengths start at 2
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (red < 0) { // padded rows (contiguous only): -red in this part's bucket (lane_pad_any picks the part)
+#if NFM_MED_LANE_PART == 5 || NFM_MED_LANE_PART == 1 // the two-lanes-per-row kernels live in parts 5 (float32) and 1 (float64)
+        if (-red > (dtype == NFM_F32 ? LanePadMax<float>::value : LanePadMax<double>::value)) {
+            if (dtype == (NFM_MED_LANE_PART == 5 ? NFM_F32 : NFM_F64)) {
+#if NFM_MED_LANE_PART == 5
+                return run_lane_pair<float>(-red, omitnan, rows, x, val, idx, s);
+#else
+                return run_lane_pair<double>(-red, omitnan, rows, x, val, idx, s);
+#endif
+            }
+            return NFM_EINVAL;
+        }
+#endif
         return dtype == NFM_F32 ? lane_pad_bucket<float>(-red, omitnan, rows, x, val, idx, s)
                                 : lane_pad_bucket<double>(-red, omitnan, rows, x, val, idx, s);
     }

@@ -43,6 +43,14 @@ namespace roww {
 
 constexpr int MPB = 16; // matrices per workgroup
 
+// The measurement knobs of this file (scripts/bench_rowwave.py: force a form, force the row-wave kernels from an
+// order up) are read only when NFM_DEBUG is set in the environment: the product's dispatch depends on ONE variable.
+static const char *dbg_env(const char *name)
+{
+    static const bool on = getenv("NFM_DEBUG") != nullptr;
+    return on ? getenv(name) : nullptr;
+}
+
 enum { RW_SOLVE_SYM = 0, RW_INV_SYM, RW_INVDIAG_SYM, RW_DET_SYM, RW_INV_GEN, RW_DET_GEN };
 
 struct RowParams {
@@ -465,8 +473,8 @@ constexpr int rww_of(int op)
 template <typename T, int N, int OP>
 static int launch(const void *a, const void *b, void *o, int64_t n, const RowParams &p, void *stream)
 {
-    static const int rows = [] { const char *e = getenv("NFM_ROWWAVE_ROWS"); return e ? atoi(e) : 0; }();
-    static const int ldsb = [] { const char *e = getenv("NFM_ROWWAVE_LDS"); return e ? atoi(e) : -1; }();
+    static const int rows = [] { const char *e = dbg_env("NFM_ROWWAVE_ROWS"); return e ? atoi(e) : 0; }();
+    static const int ldsb = [] { const char *e = dbg_env("NFM_ROWWAVE_LDS"); return e ? atoi(e) : -1; }();
     constexpr RwChoice c = rowwave_choice(sizeof(T) == 8, N, rww_of(OP));
     const int r = rows ? rows : (c.rows ? c.rows : 2);
     const bool lb = ldsb >= 0 ? ldsb != 0 : c.lds;
@@ -567,8 +575,8 @@ template struct RowWave<float>;
 
 bool rowwave_forced(bool f64, int N)
 {
-    static const int env64 = [] { const char *e = getenv("NFM_ROWWAVE_MIN_F64"); return e ? atoi(e) : 0; }();
-    static const int env32 = [] { const char *e = getenv("NFM_ROWWAVE_MIN_F32"); return e ? atoi(e) : 0; }();
+    static const int env64 = [] { const char *e = dbg_env("NFM_ROWWAVE_MIN_F64"); return e ? atoi(e) : 0; }();
+    static const int env32 = [] { const char *e = dbg_env("NFM_ROWWAVE_MIN_F32"); return e ? atoi(e) : 0; }();
     const int m = f64 ? env64 : env32;
     return m > 0 && N >= m;
 }

@@ -21,7 +21,8 @@ struct RowWave {
 };
 
 // Which cases the row-wave kernels serve, and in which form (measured on MI355X,
-// profiles/r02/rowwave_table.md: every op x order 9..16 x dtype x {lane-per-matrix, 1 / 2 / 4 rows
+// profiles/r03/rowwave_table.md -- re-measured after the pivot step lost its branch: the compact inverses now take
+// the pivot row through the LDS slot (float32 12..16: +10-20 %, float64 10..12: up to +24 %) -- and r02/rowwave_table.md: every op x order 9..16 x dtype x {lane-per-matrix, 1 / 2 / 4 rows
 // per lane, pivot row through ds_bpermute or through an LDS slot}).  rows == 0: the lane-per-matrix
 // register kernel of nfm_large.hip is faster and keeps the case.  Cases listed here are NOT
 // instantiated in nfm_large.hip any more (they were the kernels that needed scratch memory:
@@ -38,7 +39,7 @@ constexpr RwChoice rowwave_choice(bool f64, int N, int what)
     if (f64) {
         switch (what) {
         case RWW_SOLVE: return N >= 13 ? RwChoice{2, false} : N == 12 ? RwChoice{4, false} : RwChoice{0, false};
-        case RWW_INV_SYM: return N >= 13 ? RwChoice{2, false} : N >= 11 ? RwChoice{4, false} : RwChoice{0, false};
+        case RWW_INV_SYM: return N >= 13 ? RwChoice{2, true} : N >= 10 ? RwChoice{4, true} : RwChoice{0, false};
         case RWW_DET_SYM: return N >= 14 ? RwChoice{2, false} : RwChoice{0, false};
         case RWW_INV_GEN: return N >= 15 ? RwChoice{1, true} : N >= 11 ? RwChoice{2, false} : RwChoice{0, false};
         case RWW_DET_GEN: return N >= 13 ? RwChoice{1, true} : RwChoice{0, false};
@@ -46,8 +47,8 @@ constexpr RwChoice rowwave_choice(bool f64, int N, int what)
         }
     }
     switch (what) {
-    case RWW_INV_SYM: return N >= 13 ? RwChoice{4, false} : RwChoice{0, false};
-    case RWW_INV_GEN: return N >= 14 ? RwChoice{2, false} : RwChoice{0, false};
+    case RWW_INV_SYM: return N >= 16 ? RwChoice{2, true} : N >= 12 ? RwChoice{4, true} : RwChoice{0, false};
+    case RWW_INV_GEN: return N >= 14 ? RwChoice{2, true} : N == 12 ? RwChoice{4, true} : RwChoice{0, false};
     case RWW_DET_GEN: return N >= 16 ? RwChoice{2, false} : RwChoice{0, false};
     default: return {0, false};
     }

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) void sym_bcast_big_kernel(Opnd mat, Opnd vec, 
     const T *pi0 = inp.ptr ? reinterpret_cast<const T *>(inp.ptr) + o * inp.so : nullptr;
     T *po0 = reinterpret_cast<T *>(out.ptr) + o * out.so;
     const bool vstore = out.sc == 1 && out.si % (16 / (int)sizeof(T)) == 0 && (reinterpret_cast<uintptr_t>(po0) & 15) == 0;
+    // contiguous vector records are fetched with 16-byte loads; the row permutation of the factorisation is then
+    // applied through an LDS image of the workgroup's vectors ([component][lane]: conflict-free, and the permuted
+    // component index is the same in every lane) -- fetching component perm[i] of every vector straight from
+    // global memory costs M scattered 4-byte loads per vector and held the kernel at 2.1-2.6 TB/s
+    __shared__ T stage[(OP == BB_SOLVE ? MX : 1) * 256];
+    const bool vload = vec.sc == 1;
     for (int64_t tile = blockIdx.x; tile * (256 * V) < n_inner; tile += gridDim.x) {
         // the factors are re-read from LDS in every tile (broadcast reads, cheap): hoisted out of this loop, the 256
         // entries would take the whole register file and leave one wavefront per SIMD to a streaming kernel
@@ -177,9 +183,35 @@ __global__ __launch_bounds__(256) void sym_bcast_big_kernel(Opnd mat, Opnd vec, 
         for (int q = 0; q < V; ++q) {
             const int64_t n = base + q * 256;
             const T *pv = pv0 + (n < n_inner ? n : n_inner - 1) * vec.si;
+            if (vload) {
+                using VGl = typename VecOf<T>::gtype;
+                constexpr int NVl = VecOf<T>::N;
 #pragma unroll
-            for (int i = 0; i < MX; ++i)
-                if (i < M) x[q][i] = pv[(OP == BB_SOLVE ? perm[i] : i) * vec.sc]; // P v: the permuted fetch
+                for (int i = 0; i < MX; i += NVl)
+                    if (i < M) {
+                        if (i + NVl <= M) {
+                            const VGl v = *reinterpret_cast<const VGl *>(pv + i);
+#pragma unroll
+                            for (int c = 0; c < NVl; ++c) x[q][i + c] = v[c];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < NVl; ++c)
+                                if (i + c < M) x[q][i + c] = pv[i + c];
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < M) x[q][i] = pv[i * vec.sc];
+            }
+            if constexpr (OP == BB_SOLVE) { // x <- P x through the LDS image (each lane reads back its own column)
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < M) stage[i * 256 + tid] = x[q][i];
+#pragma unroll
+                for (int i = 0; i < MX; ++i)
+                    if (i < M) x[q][i] = stage[perm[i] * 256 + tid];
+            }
         }
         if constexpr (OP == BB_SOLVE) {
             // L y = P v (unit lower), then U x = y
@@ -274,7 +306,8 @@ static int sym_bcast_big(int M, int kind, int mode, int64_t no, int64_t ni, cons
 {
     constexpr int V = sizeof(T) == 4 ? 4 : 2;
     int64_t nblk = (ni + 256 * V - 1) / (256 * V);
-    const int64_t cap = (2048 + no - 1) / no; // the factorisation is paid once per workgroup: a few per CU, each streams many tiles
+    const int64_t cap = (1024 + no - 1) / no; // the factorisation is paid once per workgroup: four per CU, all resident at
+                                              // once (a second round of workgroups would pay it again), each streams many tiles
     if (nblk > cap) nblk = cap;
     if (no > 65535) return NFM_ESIZE;
     nfm_operand none = {nullptr, 0, 0, 0, 0};

@@ -53,7 +53,7 @@ def main():
     arms = (('lane', '17', '0', '0'), ('r1 bperm', '9', '1', '0'), ('r2 bperm', '9', '2', '0'), ('r4 bperm', '9', '4', '0'),
             ('r1 lds', '9', '1', '1'), ('r2 lds', '9', '2', '1'), ('r4 lds', '9', '4', '1'))
     for name, v, rows, lds in arms:
-        env = dict(os.environ, NFM_ROWWAVE_MIN_F64=v, NFM_ROWWAVE_MIN_F32=v, NFM_ROWWAVE_ROWS=rows, NFM_ROWWAVE_LDS=lds)
+        env = dict(os.environ, NFM_DEBUG='1', NFM_ROWWAVE_MIN_F64=v, NFM_ROWWAVE_MIN_F32=v, NFM_ROWWAVE_ROWS=rows, NFM_ROWWAVE_LDS=lds)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--arm'], env=env, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-3000:])

@@ -9,7 +9,7 @@ mkdir -p $O
 cd $R
 for rep in 1 2; do
   timeout -k 10 300 python scripts/bench_rowwave.py --arm > $O/lg_${TAG}_A$rep.txt 2>/dev/null; echo "A$rep rc=$?"
-  NFM_HIP_LIB=$R/nitorch_fastmath_amd/$B timeout -k 10 300 python scripts/bench_rowwave.py --arm > $O/lg_${TAG}_B$rep.txt 2>/dev/null; echo "B$rep rc=$?"
+  NFM_DEBUG=1 NFM_HIP_LIB=$R/nitorch_fastmath_amd/$B timeout -k 10 300 python scripts/bench_rowwave.py --arm > $O/lg_${TAG}_B$rep.txt 2>/dev/null; echo "B$rep rc=$?"
 done
 python - <<P
 import sys

@@ -11,3 +11,4 @@ timeout -k 10 600 python scripts/bench_qr_large.py > $O/qr_large_table_${TAG}.md
 timeout -k 10 600 python scripts/bench_median.py > $O/median_table_${TAG}.md 2>$O/median_${TAG}.err; echo "median rc=$?"; head -26 $O/median_table_${TAG}.md
 timeout -k 10 400 python scripts/bench_layouts.py > $O/layouts_table_${TAG}.md 2>/dev/null; echo "layouts rc=$?"; grep "| 12 |\|| 16 |" $O/layouts_table_${TAG}.md
 ORDERS_SYM=12,16 ORDERS_GEN=12,16 timeout -k 10 600 python scripts/bench_table.py > $O/throughput_table_${TAG}.md 2>/dev/null; echo "throughput table rc=$?"; grep -v eig_sym $O/throughput_table_${TAG}.md
+timeout -k 10 900 python scripts/bench_rowwave.py > $O/rowwave_table_${TAG}.md 2>$O/rowwave_${TAG}.err; echo "rowwave rc=$?"; tail -5 $O/rowwave_table_${TAG}.md

@@ -504,12 +504,15 @@ def test_median_row_per_lane(dev, oracle, dn):
 @pytest.mark.parametrize('dn', ['f32', 'f64'])
 def test_median_padded_row_per_lane(dev, oracle, dn):
     """rows of 129..192 (float64: 65..96) elements in batches of >= 32768 rows: one PADDED row per lane
-    (median_lane_pad_kernel: the row is padded to the next bucket length with keys that sort last) -- both
+    (median_lane_pad_kernel: the row is padded to the next bucket length with keys that sort last); rows of 193..256
+    (97..128): TWO lanes per row (median_lane_pair_kernel: each sorts a half, the halves meet in a bitonic split) -- both
     ends and the middle of every bucket, NaNs kept and omitted, all-NaN rows, infinities, signed zeros, ties;
     values and first-position indices equal to the oracle's bit for bit, and to the few-rows kernel's"""
     dtype = np.float32 if dn == 'f32' else np.float64
     lo, step, nb = (128, 16, 4) if dn == 'f32' else (64, 8, 4)
-    lengths = sorted({lo + b * step + d for b in range(nb) for d in (1, step // 2, step)} | {lo + nb * step + 1})
+    lengths = sorted({lo + b * step + d for b in range(nb) for d in (1, step // 2, step)}
+                     | {lo + nb * step + 1, lo + nb * step + 7, 2 * lo - 9, 2 * lo - 1, 2 * lo}    # two lanes per row
+                     | {2 * lo + 1})
     for red in lengths:                                   # the last one is past the limit: the wavefront-per-row kernel
         rng = np.random.default_rng(3000 + red)
         rows = 32768 + 64 + 29
