@@ -44,6 +44,10 @@ struct LdsMat {
     };
     __device__ __forceinline__ Row operator[](int i) const { return Row{p + i * ld * LANES}; }
 };
+template <class M>
+struct IsLdsMat : std::false_type {};
+template <typename T, int LANES>
+struct IsLdsMat<LdsMat<T, LANES>> : std::true_type {};
 // reflector k of a symmetric tridiagonalisation stored in row k of the matrix, right of the diagonal
 // (n - 1 - k slots for its n - 1 - k values: the sweeps of eig_sym never read the upper triangle)
 template <typename T, class M>
@@ -694,9 +698,10 @@ __device__ __forceinline__ void band_sweep_cr1(T (&d)[Dim<NT>::MAX], T (&l)[Dim<
     }
     // U <- U Q: rotation k combines columns k, k+1.  float64: column k+1 is carried in registers from one rotation
     // to the next (uc), so that a U kept in LDS is read and written once per column and sweep instead of twice (for
-    // a U in registers this is the same code as rotating in place).  float32 rotates in place: measured, the
-    // carried form of the packed rotation was 1.7x SLOWER on the LDS-resident orders (profiles/r03/qr_large_table.md).
-    if constexpr (WITH_U && sizeof(T) == 4) {
+    // a U in registers this is the same dataflow as rotating in place, and the form that allocates fewer registers:
+    // 8x8 float32 with vectors 252 against 323, two wavefronts per SIMD against one).  A float32 U kept in LDS is
+    // rotated in place: measured, the carried form of the packed rotation was 1.7x SLOWER there.
+    if constexpr (WITH_U && sizeof(T) == 4 && IsLdsMat<MU>::value) {
 #pragma unroll
         for (int k = 0; k < MX - 1; ++k) {
             if (k < m - 1) {

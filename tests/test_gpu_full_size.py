@@ -116,7 +116,7 @@ def test_median_of_a_row_longer_than_2_pow_32(dev):
     x[:1000] = -1.0
     x[-7:] = 2.0
     assert float(R.median(x)) == 0.0
-    v, i = R.median(x, return_indices=True)
+    v, i = R.median(x, dim=0, return_indices=True)            # (dim=None returns the value only, like upstream)
     assert float(v) == 0.0 and int(i) == 1000                 # first position holding the value
     x[1000:1000 + (1 << 31)] = -3.0                           # now 2^31 + 1000 of 2^32 + 12345 are below 0: still 0
     assert float(R.median(x)) == 0.0
