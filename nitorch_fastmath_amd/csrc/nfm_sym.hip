@@ -129,33 +129,64 @@ __global__ __launch_bounds__(256) void sym_bcast_big_kernel(Opnd mat, Opnd vec, 
         if (OP == BB_SOLVE && p.has_eps && ti == tj) a += (T)p.eps[ti];
     }
     if constexpr (OP == BB_SOLVE) {
-        if (tid < MX) perm[tid] = tid;
-        for (int k = 0; k < M; ++k) {
-            lu[ti * MX + tj] = a;
-            __syncthreads();
-            // pivot: first row >= k with the largest |a_rk| (every thread finds it for itself: broadcast reads)
-            int pr = k;
-            T best = fabs_(lu[k * MX + k]);
-            for (int r = k + 1; r < M; ++r) {
-                const T x = fabs_(lu[r * MX + k]);
-                if (x > best) { best = x; pr = r; }
-            }
-            // rows k and pr change places
-            if (ti == k) a = lu[pr * MX + tj];
-            else if (ti == pr) a = lu[k * MX + tj];
-            if (tid == 0 && pr != k) { const int t = perm[k]; perm[k] = perm[pr]; perm[pr] = t; }
-            const T piv = lu[pr * MX + k];               // a'[k][k]
-            const T akj = lu[pr * MX + tj];              // a'[k][j]
-            T aik = lu[ti * MX + k];                     // a'[i][k] for i > k: row i is unchanged unless i == pr
-            if (ti == pr) aik = lu[k * MX + k];
-            __syncthreads();
-            if (in && ti > k) {
-                const T l = aik / piv;
-                if (tj == k) a = l;
-                else if (tj > k) a = a - l * akj;
-            }
-        }
+        // LU with partial pivoting by ONE wavefront, without a workgroup barrier per step (round 3's first version
+        // kept element (i, j) in thread 16 i + j and went through LDS and two barriers per step: a third of the
+        // kernel's time at 4e6 vectors).  Lane l of wavefront 0 holds row l / 4, columns 4 (l % 4) .. + 3 in four
+        // registers; a step is: argmax of column k over the rows >= k (shuffles), the two rows change places
+        // (ds_bpermute), the pivot row reaches every row (ds_bpermute) and the multiplier its four lanes
+        // (quad broadcast), one fused update per register.  Then the factors go to LDS once.
         lu[ti * MX + tj] = a;
+        if (tid < MX) perm[tid] = tid;
+        __syncthreads();
+        if (tid < 64) {
+            const int lane = tid, ri = lane >> 2, g = lane & 3;
+            T r4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r4[c] = lu[ri * MX + 4 * g + c];
+            // (a run-time loop: unrolled 16 times the factorisation held 170 registers and halved the occupancy of
+            // the streaming part below, which is where the time goes)
+#pragma unroll 1
+            for (int k = 0; k < M; ++k) {
+                const int kg = k >> 2, kc = k & 3; // column k lives in register kc of the lanes with g == kg
+                const T mine_k = kc == 0 ? r4[0] : kc == 1 ? r4[1] : kc == 2 ? r4[2] : r4[3];
+                // pivot: first row >= k with the largest |a_rk|
+                T best = (g == kg && ri >= k && ri < M) ? fabs_(mine_k) : T(-1);
+                int brow = ri;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const T ob = __shfl_xor(best, off, 64);
+                    const int orow = __shfl_xor(brow, off, 64);
+                    const bool take = ob > best || (ob == best && orow < brow);
+                    best = take ? ob : best;
+                    brow = take ? orow : brow;
+                }
+                int pr = __builtin_amdgcn_readfirstlane(brow);
+                pr = (pr < k || pr >= M) ? k : pr; // (a column of NaNs compares false everywhere: keep row k)
+                // rows k and pr change places
+                const int partner = ri == k ? pr : (ri == pr ? k : ri);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r4[c] = __shfl(r4[c], partner * 4 + g, 64);
+                if (lane == 0 && pr != k) { const int t = perm[k]; perm[k] = perm[pr]; perm[pr] = t; }
+                // the pivot row for my columns, the pivot, my row's entry in column k
+                T prow[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) prow[c] = __shfl(r4[c], k * 4 + g, 64);
+                const T colk = kc == 0 ? r4[0] : kc == 1 ? r4[1] : kc == 2 ? r4[2] : r4[3];
+                const T piv = __shfl(colk, k * 4 + kg, 64);
+                const T aik = __shfl(colk, ri * 4 + kg, 64);
+                if (ri > k && ri < M) {
+                    const T l = aik / piv;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int col = 4 * g + c;
+                        if (col == k) r4[c] = l;
+                        else if (col > k) r4[c] = r4[c] - l * prow[c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lu[ri * MX + 4 * g + c] = r4[c];
+        }
         __syncthreads();
         if (tid < M) rdiag[tid] = T(1) / lu[tid * MX + tid];
     } else {
@@ -173,12 +204,9 @@ __global__ __launch_bounds__(256) void sym_bcast_big_kernel(Opnd mat, Opnd vec, 
     // global memory costs M scattered 4-byte loads per vector and held the kernel at 2.1-2.6 TB/s
     __shared__ T stage[(OP == BB_SOLVE ? MX : 1) * 256];
     const bool vload = vec.sc == 1;
-    for (int64_t tile = blockIdx.x; tile * (256 * V) < n_inner; tile += gridDim.x) {
-        // the factors are re-read from LDS in every tile (broadcast reads, cheap): hoisted out of this loop, the 256
-        // entries would take the whole register file and leave one wavefront per SIMD to a streaming kernel
-        asm volatile("" ::: "memory");
+    // the vectors of a tile as they sit in memory (16-byte loads when the records are contiguous)
+    auto fetch = [&](int64_t tile, T (&xx)[V][MX]) {
         const int64_t base = tile * (256 * V) + tid;
-        T x[V][MX];
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             const int64_t n = base + q * 256;
@@ -192,18 +220,37 @@ __global__ __launch_bounds__(256) void sym_bcast_big_kernel(Opnd mat, Opnd vec, 
                         if (i + NVl <= M) {
                             const VGl v = *reinterpret_cast<const VGl *>(pv + i);
 #pragma unroll
-                            for (int c = 0; c < NVl; ++c) x[q][i + c] = v[c];
+                            for (int c = 0; c < NVl; ++c) xx[q][i + c] = v[c];
                         } else {
 #pragma unroll
                             for (int c = 0; c < NVl; ++c)
-                                if (i + c < M) x[q][i + c] = pv[i + c];
+                                if (i + c < M) xx[q][i + c] = pv[i + c];
                         }
                     }
             } else {
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
-                    if (i < M) x[q][i] = pv[i * vec.sc];
+                    if (i < M) xx[q][i] = pv[i * vec.sc];
             }
+        }
+    };
+    // software pipeline: the next tile's vectors are on their way while this tile is solved (two wavefronts per
+    // SIMD do not hide the latency of HBM on their own)
+    T xnext[V][MX];
+    if ((int64_t)blockIdx.x * (256 * V) < n_inner) fetch(blockIdx.x, xnext);
+    for (int64_t tile = blockIdx.x; tile * (256 * V) < n_inner; tile += gridDim.x) {
+        // the factors are re-read from LDS in every tile (broadcast reads, cheap): hoisted out of this loop, the 256
+        // entries would take the whole register file and leave one wavefront per SIMD to a streaming kernel
+        asm volatile("" ::: "memory");
+        const int64_t base = tile * (256 * V) + tid;
+        T x[V][MX];
+#pragma unroll
+        for (int q = 0; q < V; ++q)
+#pragma unroll
+            for (int i = 0; i < MX; ++i) x[q][i] = xnext[q][i];
+        if ((tile + gridDim.x) * (256 * V) < n_inner) fetch(tile + gridDim.x, xnext);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
             if constexpr (OP == BB_SOLVE) { // x <- P x through the LDS image (each lane reads back its own column)
 #pragma unroll
                 for (int i = 0; i < MX; ++i)
@@ -306,8 +353,9 @@ static int sym_bcast_big(int M, int kind, int mode, int64_t no, int64_t ni, cons
 {
     constexpr int V = sizeof(T) == 4 ? 4 : 2;
     int64_t nblk = (ni + 256 * V - 1) / (256 * V);
-    const int64_t cap = (1024 + no - 1) / no; // the factorisation is paid once per workgroup: four per CU, all resident at
-                                              // once (a second round of workgroups would pay it again), each streams many tiles
+    const int64_t cap = (512 + no - 1) / no; // the factorisation is paid once per workgroup: two per CU (150-170 registers:
+                                             // two wavefronts per SIMD), all resident at once -- a second round of
+                                             // workgroups would pay it again -- each streams many tiles
     if (nblk > cap) nblk = cap;
     if (no > 65535) return NFM_ESIZE;
     nfm_operand none = {nullptr, 0, 0, 0, 0};

@@ -34,6 +34,9 @@ for M in (4, 6, 12, 16):
     vo = torch.empty(M, nodd, device=dev).copy_(vec[:nodd].T).T
     cases.append(('channel-first, odd voxel count (runs start at any alignment)', mo, vo, (K + 2 * M) * 4))
     cases.append(('one matrix, n vectors (broadcast mat)', mat[:1], vec, 2 * M * 4))
+    if M > 8:    # the same at the batch of the small orders (the matrix is factored once per workgroup: a fixed cost)
+        cases.append(('one matrix, n vectors (broadcast mat), 1.7e7 vectors', mat[:1],
+                      torch.randn(17_000_000, M, device=dev, generator=g), 2 * M * 4))
     cases.append(('n matrices, one vector (broadcast vec)', mat, vec[:1], (K + M) * 4))
     cases.append(('every other record (batch stride 2)', mat[::2], vec[::2], (K + 2 * M) * 4))
     big = torch.randn(n // 2, K, 2, device=dev, generator=g)
