@@ -476,7 +476,7 @@ static int lane_pad_any(int red, int omitnan, int64_t rows, const void *x, void 
 {
     constexpr int step = LaneMax<T>::value / kLaneParts; // 16 / 8
     const int dt = sizeof(T) == 4 ? NFM_F32 : NFM_F64;
-    if (red > LanePadMax<T>::value) // two lanes per row: part 5 (float32) / part 1 (float64)
+    if (red > LanePadMax<T>::value) // four lanes per row: part 5 (float32) / part 1 (float64)
         return sizeof(T) == 4 ? lane_part5(dt, -red, omitnan, rows, 1, x, val, idx, stream)
                               : lane_part1(dt, -red, omitnan, rows, 1, x, val, idx, stream);
     switch ((red - LaneMax<T>::value - 1) / step + LanePadBuckets<T>::first_part) {

@@ -23,6 +23,15 @@ struct Key<float> {
         const U u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
         return __int_as_float((int)u);
     }
+    // the lane kernels' hot path: the key WITHOUT the NaN rule (three instructions), NaNs found afterwards from
+    // the key itself -- a NaN of either sign lands outside the keys of -inf .. +inf
+    static __device__ __forceinline__ U bits(float x) { return (U)__float_as_int(x); }
+    static __device__ __forceinline__ U raw(float x)
+    {
+        const int u = __float_as_int(x);
+        return (U)u ^ ((U)(u >> 31) | 0x80000000u);
+    }
+    static __device__ __forceinline__ bool raw_is_nan(U k) { return k > 0xff800000u || k < 0x007fffffu; }
 };
 template <>
 struct Key<double> {
@@ -39,6 +48,13 @@ struct Key<double> {
         const U u = (k >> 63) ? (k & ~(U(1) << 63)) : ~k;
         return __longlong_as_double((long long)u);
     }
+    static __device__ __forceinline__ U bits(double x) { return (U)__double_as_longlong(x); }
+    static __device__ __forceinline__ U raw(double x)
+    {
+        const long long u = __double_as_longlong(x);
+        return (U)u ^ ((U)(u >> 63) | (U(1) << 63));
+    }
+    static __device__ __forceinline__ bool raw_is_nan(U k) { return k > 0xfff0000000000000ull || k < 0x000fffffffffffffull; }
 };
 
 // longest row sorted by one lane (nfm_reduce_median_lane.hip): the keys live in registers (128 / 2 x 64
@@ -47,11 +63,12 @@ template <typename T>
 struct LaneMax {
     static constexpr int value = sizeof(T) == 4 ? 128 : 64;
 };
-// rows up to twice that length are sorted by one lane too, padded to one of 8 bucket lengths per dtype
-// (median_lane_pad_kernel): bucket b lives in part b and is reached with red passed NEGATED
-// float32: 129..192 (4 buckets of 16, parts 0..3); float64: 65..96 (4 buckets of 8, parts 4..7).  Longer rows stay
-// on the wavefront-per-row kernel: a 256-key network is 7 700 instructions on more registers than a lane has
-// architectural ones -- a quarter of an hour of compile time per kernel for a few percent over that kernel.
+// rows up to 1.5 x that length are sorted by one lane too, padded to one of 4 bucket lengths per dtype
+// (median_lane_pad_kernel): bucket b lives in part first_part + b and is reached with red passed NEGATED
+// float32: 129..192 (4 buckets of 16, parts 0..3); float64: 65..96 (4 buckets of 8, parts 4..7).  Rows up to
+// 2 x LaneMax (193..256 / 97..128) take four lanes per row (median_lane_quad_kernel, part 5 / part 1): a 256-key
+// network in one lane is 7 700 instructions on more registers than a lane has architectural ones -- a quarter of
+// an hour of compile time per kernel.
 template <typename T>
 struct LanePadBuckets {
     static constexpr int value = 4;

@@ -101,6 +101,27 @@ __device__ __forceinline__ void sort_network(Keys<U, RED> &s)
     }
 }
 
+// The conversion of the hot path is Key::raw (three instructions, no NaN rule); whether a NaN went by is collected
+// two elements per compare (v_cmp_u of a PAIR) into a wavefront mask.  Only a wavefront that saw one runs `fix_nans`:
+// NaN keys -> the largest key, counted.  (Key::of per element -- compare, select, count -- was 6 instructions a key.)
+template <typename T>
+__device__ __forceinline__ bool either_nan(T a, T b)
+{
+    return __builtin_isunordered(a, b);
+}
+template <typename T, typename U, int RED>
+__device__ __forceinline__ unsigned fix_nans(Keys<U, RED> &s, int real)
+{
+    unsigned nan = 0;
+#pragma unroll
+    for (int i = 0; i < RED; ++i) {
+        const bool n = i < real && Key<T>::raw_is_nan(s.at(i));
+        s.at(i) = n ? ~U(0) : s.at(i);
+        nan += n ? 1u : 0u;
+    }
+    return nan;
+}
+
 constexpr int64_t kMidGrid2D = 2048; // middle-dim layout: planes at least this wide take the 2-D grid
 
 template <int RED, typename T>
@@ -146,7 +167,7 @@ __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(
         }
     }
     Keys<U, RED> s;
-    unsigned nan = 0;
+    bool seen = false; // a NaN in this lane's row
     // this lane's row: in the LDS image, or in global memory with its elements `inner` apart (two
     // pointers, so that neither becomes a flat pointer)
     const T *lown = reinterpret_cast<const T *>(smem + threadIdx.x * IO::kRowStride);
@@ -157,25 +178,29 @@ __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(
         IO::commit(smem, st);
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < RED; ++i) {
-            const T v = lown[i];
-            s.at(i) = K::of(v);
-            nan += (v != v) ? 1u : 0u;
+        for (int i = 0; i < RED; i += 2) {
+            const T v0 = lown[i], v1 = lown[i + 1 < RED ? i + 1 : i];
+            s.at(i) = K::raw(v0);
+            if (i + 1 < RED) s.at(i + 1) = K::raw(v1);
+            seen |= either_nan(v0, v1);
             // keep the scheduler from hoisting all RED reads above the conversions (2 x RED live registers)
-            if (i % 32 == 31) __builtin_amdgcn_sched_barrier(0);
+            if (i % 32 == 30) __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         // (lanes past the end redo a valid row and store nothing)
         if (grid2d && mo * inner >= rows) mo = 0;
         gown = x + (mo * RED) * inner + (mi < inner ? mi : inner - 1);
 #pragma unroll
-        for (int i = 0; i < RED; ++i) {
-            const T v = NFM_LDG(gown + i * inner);
-            s.at(i) = K::of(v);
-            nan += (v != v) ? 1u : 0u;
-            if (i % 32 == 31) __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < RED; i += 2) {
+            const T v0 = NFM_LDG(gown + i * inner), v1 = NFM_LDG(gown + (i + 1 < RED ? i + 1 : i) * inner);
+            s.at(i) = K::raw(v0);
+            if (i + 1 < RED) s.at(i + 1) = K::raw(v1);
+            seen |= either_nan(v0, v1);
+            if (i % 32 == 30) __builtin_amdgcn_sched_barrier(0);
         }
     }
+    unsigned nan = 0;
+    if (__builtin_expect(__any(seen), 0)) nan = fix_nans<T>(s, RED);
     sort_network<U, RED>(s);
     const unsigned count = omitnan ? (unsigned)RED - nan : (unsigned)RED;
     const bool want_nan = (!omitnan && nan > 0) || count == 0;
@@ -191,17 +216,24 @@ __global__ __launch_bounds__((LaneTile<RED, T>::value)) void median_lane_kernel(
         if (idx != nullptr) { // uniform
             // first position holding the chosen key (a NaN result: the first NaN): the row is read again
             // (LDS image / global memory), so the unsorted keys need not stay in registers during the sort
+            // A value that is not a NaN is looked for by its bit pattern (compare + select per element); a NaN
+            // result by its key, any payload (a wavefront with such a row: rare, a loop that is not unrolled).
             int first = 0;
-            if (!mid) {
+            if (__builtin_expect(__any(want_nan), 0)) {
+#pragma unroll 1
+                for (int i = RED - 1; i >= 0; --i) first = (K::of(mid ? gown[i * inner] : lown[i]) == chosen) ? i : first;
+            } else if (!mid) {
+                const U target = K::bits(K::back(chosen));
 #pragma unroll
                 for (int i = RED - 1; i >= 0; --i) {
-                    first = (K::of(lown[i]) == chosen) ? i : first;
+                    first = (K::bits(lown[i]) == target) ? i : first;
                     if (i % 32 == 0) __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
+                const U target = K::bits(K::back(chosen));
 #pragma unroll
                 for (int i = RED - 1; i >= 0; --i) {
-                    first = (K::of(gown[i * inner]) == chosen) ? i : first;
+                    first = (K::bits(gown[i * inner]) == target) ? i : first;
                     if (i % 32 == 0) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -256,29 +288,37 @@ __global__ __launch_bounds__(64) void median_lane_pad_kernel(const T *__restrict
     const bool live = row < rows;
     const T *own = x + (live ? row : rows - 1) * (int64_t)red;
     Keys<U, RED> s;
-    unsigned nan = 0;
+    bool seen = false; // a NaN in this lane's row
+    // every load of the row is issued before the first conversion (one round trip to memory, not one per group: a
+    // kernel with one or two wavefronts per SIMD has nothing else to hide them behind); the conversions then reuse
+    // the registers of the loaded words.  (Plain loads, not the nontemporal ones of the streaming kernels: the
+    // eight 16-byte loads a lane makes to one 128-byte line come from eight instructions, and the line has to stay
+    // in the cache between them.)
+    VG words[SURE / V];
+    T tail[RED - SURE];
+#pragma unroll
+    for (int i = 0; i < SURE; i += V) words[i / V] = *reinterpret_cast<const VG *>(own + i);
+#pragma unroll
+    for (int i = SURE; i < RED; ++i) tail[i - SURE] = own[i < red ? i : red - 1]; // no branch: a slot past the row re-reads the last element
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < SURE; i += V) {
-        // (plain loads, not the nontemporal ones of the streaming kernels: the eight 16-byte loads a lane makes
-        // to one 128-byte line come from eight instructions, and the line has to stay in the cache between them)
-        const VG v = *reinterpret_cast<const VG *>(own + i);
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-            s.at(i + q) = K::of(v[q]);
-            nan += (v[q] != v[q]) ? 1u : 0u;
+        for (int q = 0; q < V; q += 2) {
+            s.at(i + q) = K::raw(words[i / V][q]);
+            s.at(i + q + 1) = K::raw(words[i / V][q + 1]);
+            seen |= either_nan(words[i / V][q], words[i / V][q + 1]);
         }
-        if (i % 32 == 32 - V) __builtin_amdgcn_sched_barrier(0); // keep the loads from piling up ahead of the conversions
     }
 #pragma unroll
     for (int i = SURE; i < RED; ++i) {
-        if (i < red) { // uniform
-            const T v = own[i];
-            s.at(i) = K::of(v);
-            nan += (v != v) ? 1u : 0u;
-        } else {
-            s.at(i) = ~U(0); // padding: the NaN key, sorts last (not counted in `nan`)
-        }
+        const T v = tail[i - SURE];
+        const U kv = K::raw(v);
+        s.at(i) = i < red ? kv : ~U(0); // padding: the NaN key, sorts last (not counted in `nan`)
+        seen |= v != v;
     }
+    unsigned nan = 0;
+    if (__builtin_expect(__any(seen), 0)) nan = fix_nans<T>(s, red);
     sort_network<U, RED>(s);
     const unsigned count = omitnan ? (unsigned)red - nan : (unsigned)red;
     const bool want_nan = (!omitnan && nan > 0) || count == 0;
@@ -291,9 +331,27 @@ __global__ __launch_bounds__(64) void median_lane_pad_kernel(const T *__restrict
     if (want_nan) chosen = ~U(0);
     if (live) {
         val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
-        if (idx != nullptr) { // uniform: first position holding the chosen key (a NaN result: the first NaN)
+        if (idx != nullptr) { // uniform: first position holding the chosen value, by its bit pattern (a NaN result:
+                              // the first NaN of any payload, by its key); the row is read again
             int first = 0;
-            for (int i = red - 1; i >= 0; --i) first = (K::of(own[i]) == chosen) ? i : first;
+            if (__builtin_expect(__any(want_nan), 0)) {
+#pragma unroll 1
+                for (int i = red - 1; i >= 0; --i) first = (K::of(own[i]) == chosen) ? i : first;
+            } else {
+                const U target = K::bits(K::back(chosen));
+#pragma unroll
+                for (int i = RED - 1; i >= SURE; --i) {
+                    const U b = K::bits(own[i < red ? i : red - 1]);
+                    first = (i < red && b == target) ? i : first;
+                }
+#pragma unroll
+                for (int i = SURE - V; i >= 0; i -= V) {
+                    const VG v = *reinterpret_cast<const VG *>(own + i);
+#pragma unroll
+                    for (int q = V - 1; q >= 0; --q) first = (K::bits(v[q]) == target) ? i + q : first;
+                    if (i % 32 == 0) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             idx[row] = first;
         }
     }
@@ -324,94 +382,101 @@ static int lane_pad_bucket(int red, int omitnan, int64_t rows, const void *x, vo
 }
 
 // ---------------------------------------------------------------------------------------------
-// rows of LanePadMax+1 .. 2 LaneMax elements (float32: 193..256, float64: 97..128): TWO LANES PER ROW.  Each lane
-// of a pair sorts one half of the row (H = LaneMax keys, the network the exact-length kernels use), then the two
-// sorted halves A, B are combined without a merge: the H smallest keys of their union are
-// { min(A[i], B[H-1-i]) : i < H } (the first half of a bitonic split), so the key of rank H-1 of the 2 H slots is
-// max_i min(A[i], B[H-1-i]) -- H v_min with the partner's register through DPP (quad_perm [1,0,3,2]) and H-1 v_max.
-// The rank wanted, k = (count-1)/2 of `count` real keys, is MADE to be H-1: the 2 H - count slots that hold no real
-// key (padding, omitted NaNs) are filled with H-1-k smallest keys (0: never a real key) and largest keys (~0) for
-// the rest; k + (H-1-k) = H-1.  With no NaN in the wavefront the split is the same for every row and is decided
-// per slot index; rows with omitted NaNs turn that many more of their NaN keys into smallest keys (a vote, a
-// sequential pass).  ~27 compare-exchange instructions per key against ~30 for one lane sorting 2 H keys, on half
-// the registers (three wavefronts per SIMD instead of one) and at the compile time of the H-key network.
-__device__ __forceinline__ unsigned pair_swap32(unsigned v)
+// rows of LanePadMax+1 .. 2 LaneMax elements (float32: 193..256, float64: 97..128): FOUR LANES PER ROW (a quad).
+// Each lane sorts a quarter of the row (H = LaneMax / 2 keys) with the merge-exchange network; the quarters then
+// meet in two bitonic steps, partner registers coming through DPP:
+//   level 1, lanes (0,1) and (2,3): for two sorted runs A, B the H smallest keys of their union are
+//     { min(A[i], B[H-1-i]) } and the H largest { max(A[i], B[H-1-i]) } -- the even lane keeps the first set, the
+//     odd lane the second; each set is a bitonic sequence, which log2(H) half-cleaner stages sort inside the lane;
+//   level 2, lanes (0,3) and (1,2): with AB and CD now sorted across two lanes each, the key of rank 2H-1 of the
+//     4 H slots is max_i min(AB[i], CD[2H-1-i]): H v_min per lane against the mirrored partner, a running v_max,
+//     and a maximum over the quad.
+// The rank wanted, k = (count-1)/2 of `count` real keys, is MADE to be 2H-1: the 4 H - count slots that hold no real
+// key (padding, omitted NaNs) are filled with 2H-1-k smallest keys (0: never a real key) and largest keys (~0) for
+// the rest.  With no omitted NaN in the wavefront the split is the same for every row and decided per slot index;
+// rows with omitted NaNs turn that many more of their NaN keys into smallest keys (a vote, a sequential pass).
+// ~34 instructions per key on ~100 registers: several wavefronts per SIMD hide the row fetch, which a lane does
+// itself with element-aligned 16-byte loads.  (Two lanes per row, 128 keys each, was built first: 29 instructions
+// per key but 260 registers, one wavefront per SIMD, 39 % of its time waiting for its loads: 1.9-2.05 TB/s.)
+template <int CTRL>
+__device__ __forceinline__ unsigned quad_dpp32(unsigned v)
 {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
-template <typename U>
-__device__ __forceinline__ U pair_swap(U v)
+template <int CTRL, typename U>
+__device__ __forceinline__ U quad_dpp(U v)
 {
     if constexpr (sizeof(U) == 4) {
-        return (U)pair_swap32((unsigned)v);
+        return (U)quad_dpp32<CTRL>((unsigned)v);
     } else {
-        const unsigned lo = pair_swap32((unsigned)v), hi = pair_swap32((unsigned)((unsigned long long)v >> 32));
+        const unsigned lo = quad_dpp32<CTRL>((unsigned)v), hi = quad_dpp32<CTRL>((unsigned)((unsigned long long)v >> 32));
         return (U)(((unsigned long long)hi << 32) | lo);
     }
 }
+constexpr int kQuadSwap1 = 0xB1;   // quad_perm [1,0,3,2]: lane ^ 1
+constexpr int kQuadSwap2 = 0x4E;   // quad_perm [2,3,0,1]: lane ^ 2
+constexpr int kQuadMirror = 0x1B;  // quad_perm [3,2,1,0]: lane ^ 3
 
 template <typename T>
-__global__ __launch_bounds__(64) void median_lane_pair_kernel(const T *__restrict__ x, int64_t rows, int red, int omitnan,
+__global__ __launch_bounds__(64) void median_lane_quad_kernel(const T *__restrict__ x, int64_t rows, int red, int omitnan,
                                                               T *__restrict__ val, int64_t *__restrict__ idx)
 {
     using K = Key<T>;
     using U = typename K::U;
     using VG = typename VecOf<T>::gtype;
     constexpr int V = VecOf<T>::N;
-    constexpr int H = LaneMax<T>::value;  // key slots per lane
-    const int h = threadIdx.x & 1;
-    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 1);
+    constexpr int H = LaneMax<T>::value / 2; // key slots per lane
+    constexpr int SURE = (3 * H) / 4;        // real elements every lane of this kernel has (red > 3 H)
+    static_assert(SURE % V == 0 && (H & (H - 1)) == 0, "vector loads cover the sure part; H is a power of two");
+    const int q = threadIdx.x & 3;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool live = row < rows;
-    // the row is split in the middle: lane 0 of the pair takes the first mine0 = ceil(red / 2) elements, lane 1 the
-    // other floor(red / 2) (3 H / 4 < mine <= H each), so both fetch with the same 16-byte loads up to `vend` and
-    // at most V + 1 single elements after it; their remaining slots are padding
-    const int mine0 = (red + 1) / 2, mine1 = red / 2;
-    const int mine = h ? mine1 : mine0;
-    const int vend = (mine1 / V) * V;  // uniform
-    const T *own = x + (live ? row : rows - 1) * (int64_t)red + h * mine0;
-    // padding: 2 H - red slots, pads0 of them in lane 0; the first lo0 = H-1 - (red-1)/2 of them (lane 0's first) hold
-    // the smallest key, the others the largest: the split of a row without omitted NaNs (the same for every row)
-    const int lo0 = (H - 1) - (red - 1) / 2;
-    const int pads0 = H - mine0;
-    const int z0 = lo0 < pads0 ? lo0 : pads0;
-    const int zmine = h ? lo0 - z0 : z0; // smallest-key slots among this lane's padding (its first zmine padding slots)
+    // the row is cut in four: lane q takes mine(q) = (red + 3 - q) / 4 elements from off(q)
+    const int m0 = (red + 3) / 4, m1 = (red + 2) / 4, m2 = (red + 1) / 4, m3 = red / 4;
+    const int mine = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
+    const int off = q == 0 ? 0 : q == 1 ? m0 : q == 2 ? m0 + m1 : m0 + m1 + m2;
+    const T *own = x + (live ? row : rows - 1) * (int64_t)red + off;
+    // padding: 4 H - red slots, H - mine(q) in lane q; the first lo0 = 2H-1 - (red-1)/2 of them (lane 0's first, then
+    // lane 1's, ...) hold the smallest key, the others the largest: the split of a row without omitted NaNs
+    const int lo0 = (2 * H - 1) - (red - 1) / 2;
+    const int before = q == 0 ? 0 : q == 1 ? H - m0 : q == 2 ? 2 * H - m0 - m1 : 3 * H - m0 - m1 - m2; // padding slots of the lanes before mine
+    const int zmine = lo0 - before; // smallest-key slots among this lane's padding (<= 0: none; >= its count: all)
     Keys<U, H> s;
-    unsigned nan = 0;
+    bool seen = false; // a NaN in this lane's part of the row
 #pragma unroll
-    for (int i = 0; i < H; i += V) {
-        if (i < vend) { // uniform
-            const VG v = *reinterpret_cast<const VG *>(own + i); // plain loads: a lane walks its cache lines with consecutive loads
+    for (int i = 0; i < SURE; i += V) {
+        const VG v = *reinterpret_cast<const VG *>(own + i); // plain loads: a lane walks its cache lines with consecutive loads
 #pragma unroll
-            for (int q = 0; q < V; ++q) {
-                s.at(i + q) = K::of(v[q]);
-                nan += (v[q] != v[q]) ? 1u : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < V; ++q) {
-                const int e = i + q;
-                U key = (e - mine < zmine) ? U(0) : ~U(0); // padding slot number e - mine of this lane
-                if (e < mine0) { // uniform: at most V + 1 elements past vend are real in either lane
-                    const bool real = e < mine;
-                    const T v = own[real ? e : mine - 1];
-                    key = real ? K::of(v) : key;
-                    nan += (real && v != v) ? 1u : 0u;
-                }
-                s.at(e) = key;
-            }
+        for (int c = 0; c < V; c += 2) {
+            s.at(i + c) = K::raw(v[c]);
+            s.at(i + c + 1) = K::raw(v[c + 1]);
+            seen |= either_nan(v[c], v[c + 1]);
         }
-        if (i % 32 == 32 - V) __builtin_amdgcn_sched_barrier(0);
     }
-    const unsigned nan_row = nan + pair_swap(nan);
+#pragma unroll
+    for (int e = SURE; e < H; ++e) { // single, address-clamped loads and a select: no branch, all in flight together
+        const bool real = e < mine;
+        const T v = own[real ? e : mine - 1]; // (a padding slot re-reads the last element: its NaN is seen anyway)
+        const U pad = (e - mine < zmine) ? U(0) : ~U(0); // padding slot number e - mine of this lane
+        const U kv = K::raw(v); // (both arms evaluated ahead of the select: a call in an arm becomes a branch, and a
+                                // branch per slot is a load, a wait, a load, a wait ...)
+        s.at(e) = real ? kv : pad;
+        seen |= v != v;
+    }
+    unsigned nan = 0;
+    if (__builtin_expect(__any(seen), 0)) nan = fix_nans<T>(s, mine);
+    const unsigned n1 = nan + quad_dpp32<kQuadSwap1>(nan);
+    const unsigned nan_row = n1 + quad_dpp32<kQuadSwap2>(n1);
     const unsigned count = omitnan ? (unsigned)red - nan_row : (unsigned)red;
     const bool want_nan = (!omitnan && nan_row > 0) || count == 0;
     if (__builtin_expect(__any(omitnan && nan_row > 0 && count > 0), 0)) {
         // omitted NaNs lower the rank: k = (count-1)/2, so (red-1)/2 - k more smallest keys are needed; they are
-        // made out of this row's NaN keys, the first lane of the pair first
+        // made out of this row's NaN keys, lane 0 of the quad first
         const int more = (omitnan && count > 0) ? (int)((unsigned)(red - 1) / 2 - (count - 1) / 2) : 0;
-        const int nan0 = (int)(h ? nan_row - nan : nan);
-        const int take0 = more < nan0 ? more : nan0; // lane 0's share
-        int budget = h ? more - take0 : take0;
+        const int n_0 = (int)quad_dpp32<0x00>(nan), n_1 = (int)quad_dpp32<0x55>(nan), n_2 = (int)quad_dpp32<0xAA>(nan); // lanes 0, 1, 2 of the quad
+        const int prior = q == 0 ? 0 : q == 1 ? n_0 : q == 2 ? n_0 + n_1 : n_0 + n_1 + n_2;
+        int budget = more - prior;
+        budget = budget < 0 ? 0 : budget;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
             const bool real_nan = i < mine && s.at(i) == ~U(0);
@@ -421,23 +486,68 @@ __global__ __launch_bounds__(64) void median_lane_pair_kernel(const T *__restric
         }
     }
     sort_network<U, H>(s);
-    // rank H-1 of the pair's 2 H slots
+    // level 1: the even lane of a pair keeps the H smallest of the pair's keys, the odd lane the H largest
+    {
+        const bool odd = (q & 1) != 0;
+        U t[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) t[i] = quad_dpp<kQuadSwap1>(s.at(H - 1 - i));
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const U a = s.at(i), lo = a < t[i] ? a : t[i], hi = a < t[i] ? t[i] : a;
+            s.at(i) = odd ? hi : lo;
+        }
+        // a bitonic sequence: log2(H) half-cleaner stages sort it
+#pragma unroll
+        for (int d = H / 2; d >= 1; d /= 2)
+#pragma unroll
+            for (int i = 0; i < H; ++i)
+                if ((i & d) == 0) cmpxchg(s.at(i), s.at(i + d));
+    }
+    // level 2: rank 2H-1 of the quad's 4 H slots
     U chosen = U(0);
 #pragma unroll
     for (int i = 0; i < H; ++i) {
-        const U other = pair_swap(s.at(H - 1 - i));
+        const U other = quad_dpp<kQuadMirror>(s.at(H - 1 - i));
         const U m = s.at(i) < other ? s.at(i) : other;
         chosen = m > chosen ? m : chosen;
+    }
+    {
+        const U o1 = quad_dpp<kQuadSwap1>(chosen);
+        chosen = o1 > chosen ? o1 : chosen;
+        const U o2 = quad_dpp<kQuadSwap2>(chosen);
+        chosen = o2 > chosen ? o2 : chosen;
     }
     if (want_nan) chosen = ~U(0);
     if (live) {
         int first = 0x7fffffff;
-        if (idx != nullptr) { // uniform: first position holding the chosen key (a NaN result: the first NaN)
-            for (int i = mine - 1; i >= 0; --i) first = (K::of(own[i]) == chosen) ? h * mine0 + i : first;
-            const int of = (int)pair_swap((unsigned)first);
-            first = of < first ? of : first;
+        if (idx != nullptr) { // uniform: first position holding the chosen value, by its bit pattern (a NaN result:
+                              // the first NaN of any payload, by its key); the row is read again
+            if (__builtin_expect(__any(want_nan), 0)) {
+#pragma unroll 1
+                for (int i = mine - 1; i >= 0; --i) first = (K::of(own[i]) == chosen) ? i : first;
+            } else {
+                const U target = K::bits(K::back(chosen));
+#pragma unroll
+                for (int e = H - 1; e >= SURE; --e) {
+                    const bool real = e < mine;
+                    const U b = K::bits(own[real ? e : mine - 1]);
+                    first = (real && b == target) ? e : first;
+                }
+#pragma unroll
+                for (int i = SURE - V; i >= 0; i -= V) {
+                    const VG v = *reinterpret_cast<const VG *>(own + i);
+#pragma unroll
+                    for (int c = V - 1; c >= 0; --c) first = (K::bits(v[c]) == target) ? i + c : first;
+                }
+            }
+            first = first == 0x7fffffff ? first : first + off;
+            const int f1 = (int)quad_dpp32<kQuadSwap1>((unsigned)first);
+            first = f1 < first ? f1 : first;
+            const int f2 = (int)quad_dpp32<kQuadSwap2>((unsigned)first);
+            first = f2 < first ? f2 : first;
         }
-        if (h == 0) {
+        if (q == 0) {
             val[row] = want_nan ? (T)__builtin_nanf("") : K::back(chosen);
             if (idx != nullptr) idx[row] = first;
         }
@@ -445,12 +555,12 @@ __global__ __launch_bounds__(64) void median_lane_pair_kernel(const T *__restric
 }
 
 template <typename T>
-static int run_lane_pair(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
+static int run_lane_quad(int red, int omitnan, int64_t rows, const void *x, void *val, void *idx, hipStream_t s)
 {
     if (red <= LanePadMax<T>::value || red > 2 * LaneMax<T>::value) return NFM_EINVAL;
-    const int64_t nblk = (rows + 31) / 32;
+    const int64_t nblk = (rows + 15) / 16;
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
-    hipLaunchKernelGGL((median_lane_pair_kernel<T>), dim3((unsigned)nblk), dim3(64), 0, s, static_cast<const T *>(x), rows,
+    hipLaunchKernelGGL((median_lane_quad_kernel<T>), dim3((unsigned)nblk), dim3(64), 0, s, static_cast<const T *>(x), rows,
                        red, omitnan, static_cast<T *>(val), static_cast<int64_t *>(idx));
     return launch_status();
 }
@@ -476,13 +586,13 @@ int NFM_MED_CAT(lane_part, NFM_MED_LANE_PART)(int dtype, int red, int omitnan, i
     constexpr int first = NFM_MED_LANE_PART >= 2 ? NFM_MED_LANE_PART : NFM_MED_LANE_PART + kLaneParts; // lengths start at 2
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (red < 0) { // padded rows (contiguous only): -red in this part's bucket (lane_pad_any picks the part)
-#if NFM_MED_LANE_PART == 5 || NFM_MED_LANE_PART == 1 // the two-lanes-per-row kernels live in parts 5 (float32) and 1 (float64)
+#if NFM_MED_LANE_PART == 5 || NFM_MED_LANE_PART == 1 // the four-lanes-per-row kernels live in parts 5 (float32) and 1 (float64)
         if (-red > (dtype == NFM_F32 ? LanePadMax<float>::value : LanePadMax<double>::value)) {
             if (dtype == (NFM_MED_LANE_PART == 5 ? NFM_F32 : NFM_F64)) {
 #if NFM_MED_LANE_PART == 5
-                return run_lane_pair<float>(-red, omitnan, rows, x, val, idx, s);
+                return run_lane_quad<float>(-red, omitnan, rows, x, val, idx, s);
 #else
-                return run_lane_pair<double>(-red, omitnan, rows, x, val, idx, s);
+                return run_lane_quad<double>(-red, omitnan, rows, x, val, idx, s);
 #endif
             }
             return NFM_EINVAL;
