@@ -362,6 +362,136 @@ __device__ __forceinline__ void ge_solve(T (&a)[N][N], T (&b)[N][NR])
     }
 }
 
+// ----------------------------------------------------------------------------
+// symmetric positive definite matrices in COMPACT storage: A = U^T D U, U unit upper triangular
+// ----------------------------------------------------------------------------
+// The sym_* functions are fed Hessians: symmetric positive definite in practice.  For those the factorisation
+// without pivoting is backward stable (no growth: |u_kj|^2 d_k <= a_jj), works on the N (N + 1) / 2 stored
+// values in place and costs N^3 / 6 fma -- against N^2 registers, 2 N^3 / 3 fma and as many selects again for the
+// run-time row exchanges of the pivoted LU the reference takes (`torch.linalg.solve`, `_impl/sym.py:392-396`).
+// `ldl_factor` reports whether every pivot was positive (Sylvester: exactly the positive definite matrices); the
+// callers vote over the wavefront and redo the whole wavefront with the pivoted elimination when one matrix was not.
+// After the call: m[i] = 1 / d_i, m[sym_idx(i, j)] = u_ij (i < j).
+template <typename T, int N>
+__device__ __forceinline__ bool ldl_factor(T (&m)[sym_k(N)], T &det)
+{
+    // (loops over literal bounds with a predicate inside: a bound that depends on an outer induction variable is
+    // not a constant until the outer loop is unrolled, the inner loop then misses the unroller's first pass, and
+    // the array stays in scratch memory -- seen at order 10, and with ldl_inverse at every order)
+    bool ok = true;
+    det = T(1);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const T d = m[k];
+        ok = ok && d > T(0); // (a NaN fails)
+        det *= d;
+        const T r = T(1) / d;
+        m[k] = r;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i > k) {
+                const T u = m[sym_idx(N, k, i)] * r; // u_ki; the row k itself stays unscaled until its last use
+                m[i] = fma_(-u, m[sym_idx(N, k, i)], m[i]);
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (j > i) m[sym_idx(N, i, j)] = fma_(-u, m[sym_idx(N, k, j)], m[sym_idx(N, i, j)]);
+            }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i > k) m[sym_idx(N, k, i)] *= r;
+    }
+    return ok;
+}
+
+// x = A^-1 v from the factors: U^T y = v, z = D^-1 y, U x = z
+template <typename T, int N>
+__device__ __forceinline__ void ldl_solve(const T (&m)[sym_k(N)], const T (&v)[N], T (&x)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = v[i];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j > k) x[j] = fma_(-m[sym_idx(N, k, j)], x[k], x[j]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] *= m[k];
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j > k) x[k] = fma_(-m[sym_idx(N, k, j)], x[j], x[k]);
+}
+
+// U -> W = U^-1 in place (unit upper triangular, compact storage): W_ij = -(u_ij + sum_{i<k<j} W_ik u_kj); row i
+// uses the rows below it as they were and its own earlier columns as they have become
+template <typename T, int N>
+__device__ __forceinline__ void ldl_unit_inverse(T (&m)[sym_k(N)])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j > i) {
+                T s = m[sym_idx(N, i, j)];
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (k > i && k < j) s = fma_(m[sym_idx(N, i, k)], m[sym_idx(N, k, j)], s);
+                m[sym_idx(N, i, j)] = -s;
+            }
+        // (rows are independent of each other's results: left alone, the scheduler interleaves them all and holds
+        // U and W at the same time -- 295 registers instead of 175 at order 16; one row at a time)
+        if (N > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the factors of ldl_factor -> A^-1 = W D^-1 W^T in compact storage, in place: N^3 / 3 fma more
+//   (A^-1)_ij = z_j + sum_{k>j} z_k W_jk,  (A^-1)_ii = 1/d_i + sum_{k>i} z_k W_ik,  z_k = W_ik / d_k
+template <typename T, int N>
+__device__ __forceinline__ void ldl_inverse(T (&m)[sym_k(N)])
+{
+    ldl_unit_inverse<T, N>(m);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T z[N];
+        T dsum = m[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            z[k] = T(0);
+            if (k > i) {
+                z[k] = m[sym_idx(N, i, k)] * m[k];
+                dsum = fma_(z[k], m[sym_idx(N, i, k)], dsum);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j > i) {
+                T s = z[j];
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (k > j) s = fma_(z[k], m[sym_idx(N, j, k)], s);
+                m[sym_idx(N, i, j)] = s;
+            }
+        m[i] = dsum;
+        if (N > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// diagonal of A^-1 only
+template <typename T, int N>
+__device__ __forceinline__ void ldl_inverse_diag(T (&m)[sym_k(N)], T (&dg)[N])
+{
+    ldl_unit_inverse<T, N>(m);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T s = m[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (k > i) s = fma_(m[sym_idx(N, i, k)] * m[k], m[sym_idx(N, i, k)], s);
+        dg[i] = s;
+    }
+}
+
 // In-place Gauss-Jordan inverse with partial pivoting (N^2 registers, no second
 // matrix): row swaps during elimination, the matching column swaps undone at the
 // end.  Singular input -> inf/NaN, like the reference (no error).

@@ -1,0 +1,325 @@
+// nfm_spd.hip -- orders 9..16 of sym_solve / sym_invert / sym_det on contiguous compact records:
+// POSITIVE DEFINITE FIRST.
+//
+// The matrices these functions are fed are Hessians: symmetric positive definite.  The reference sends every
+// order > 4 through `torch.linalg.solve` of the densified matrix (`_impl/sym.py:392-396`: LU with partial pivoting),
+// and so did this library: N^2 registers, 2 N^3 / 3 fma and -- registers cannot be indexed at run time -- as many
+// selects again for the row exchanges (16x16 float32 solve: 6 650 instructions, 3 185 of them v_cndmask, one
+// wavefront per SIMD; float64 13..16 do not fit a lane at all and went to the one-matrix-per-16-lanes kernels).
+// A positive definite matrix needs none of that: A = U^T D U without pivoting is backward stable, works on the
+// N (N + 1) / 2 stored values in place and costs N^3 / 6 fma (nfm_smallmat.hpp: ldl_factor).
+//
+//   * one matrix per lane, the compact record in registers; a wavefront is a workgroup and moves its 64 records
+//     through an LDS image with whole-line accesses (float64 orders 13..16, whose image would be 46-70 KiB: every
+//     lane fetches and stores its records itself with element-aligned 16-byte accesses, all loads in flight
+//     before the first use);
+//   * every pivot positive <=> the matrix is positive definite (Sylvester).  The wavefront votes: when every
+//     matrix passed, the lanes finish (solve: two triangular sweeps; inverse: W = U^-1, then W D^-1 W^T, in
+//     place; determinant: the product of the pivots) and store;
+//   * a wavefront with ONE matrix that did not pass drops its work and redoes its 64 matrices with the pivoted
+//     elimination of nfm_rowwave (4 lanes per matrix, 16 matrices per pass, straight from global memory): the
+//     answer for indefinite, singular and NaN input is what it was before this file existed.
+//
+// Results differ from the LU's in rounding only (both are backward stable on these matrices); parity is asserted
+// through the tolerance of the tests, like every result beyond the closed forms.
+#include "nfm_rowwave_core.hpp"
+#include "nfm_spd.hpp"
+
+#ifndef NFM_SPD_PART
+#error "compile with -DNFM_SPD_PART=0..7"
+#endif
+
+namespace nfm {
+namespace spd {
+
+using roww::RowParams;
+
+constexpr int roww_op(int op)
+{
+    return op == SP_SOLVE ? roww::RW_SOLVE_SYM : op == SP_INV ? roww::RW_INV_SYM
+           : op == SP_INVDIAG ? roww::RW_INVDIAG_SYM : roww::RW_DET_SYM;
+}
+
+// a lane's record <-> registers: element-aligned 16-byte accesses and a tail of single elements.  PLAIN accesses:
+// the eight a lane makes to one 128-byte line come from eight instructions, the line has to stay in the cache
+// between them (nontemporal loads fetched it eight times: nfm_reduce_median_lane.hip measured 1.65 against 3.5 TB/s)
+template <typename T, int C>
+__device__ __forceinline__ void load_record(const T *__restrict__ p, T (&r)[C])
+{
+    using VG = typename VecOf<T>::gtype;
+    constexpr int V = VecOf<T>::N, F = C / V;
+    VG w[F > 0 ? F : 1];
+#pragma unroll
+    for (int i = 0; i < F; ++i) w[i] = *reinterpret_cast<const VG *>(p + i * V);
+#pragma unroll
+    for (int i = F * V; i < C; ++i) r[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int q = 0; q < V; ++q) r[i * V + q] = w[i][q];
+}
+template <typename T, int C>
+__device__ __forceinline__ void store_record(T *__restrict__ p, const T (&r)[C])
+{
+    using VG = typename VecOf<T>::gtype;
+    constexpr int V = VecOf<T>::N, F = C / V;
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        VG w;
+#pragma unroll
+        for (int q = 0; q < V; ++q) w[q] = r[i * V + q];
+        *reinterpret_cast<VG *>(p + i * V) = w;
+    }
+#pragma unroll
+    for (int i = F * V; i < C; ++i) p[i] = r[i];
+}
+
+// The float64 kernels of the top orders hold more than 256 values per lane: they are compiled for ONE wavefront per
+// SIMD, which opens the whole 512-register file (without it the backend stops at 256 and spills to scratch).  The
+// others carry no bound: any bound is also a licence -- at `amdgpu_waves_per_eu(2)` the scheduler stretched the
+// fallback (70-120 registers on its own) to 256 and spilled.
+template <typename T, int N>
+constexpr int spd_max_waves()
+{
+    return (sizeof(T) == 8 && N >= 14) ? 1 : 8;
+}
+
+// how the records travel: through an LDS image of the wavefront's 64 records (whole-line accesses), or lane by lane
+// with element-aligned 16-byte accesses.  The image of float64 orders 13..16 is 46-70 KiB a wavefront -- two or
+// three wavefronts a CU -- so those go lane by lane (measured there: 0.60-0.65 of the roofline); everywhere else the
+// image wins (float32 12x12 inverse: 0.35 lane by lane -- the eight 16-byte stores a lane makes to a 128-byte line
+// are eight transactions at the L2 -- against 0.42 for the kernel this file replaces).
+template <typename T, int N>
+constexpr bool spd_tiled()
+{
+    return sizeof(T) == 4 || N <= 12;
+}
+template <typename T, int N, int OP>
+constexpr size_t spd_lds_bytes()
+{
+    constexpr int ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? sym_k(N) : OP == SP_INVDIAG ? N : 1;
+    size_t b = roww::tile_lds_bytes<T, N, roww_op(OP), false, (sizeof(T) == 8 ? 4 : 16)>();
+    if (spd_tiled<T, N>()) {
+        const size_t tm = TileIO<T, sym_k(N), 64>::kLdsBytes, tr = TileIO<T, ROUT, 64>::kLdsBytes;
+        const size_t tv = TileIO<T, N, 64>::kLdsBytes;
+        b = b > tm ? b : tm;
+        b = b > tr ? b : tr;
+        b = b > tv ? b : tv;
+    }
+    return b;
+}
+
+template <typename T, int N, int OP>
+__global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __launch_bounds__(64) void spd_kernel(const T *__restrict__ A, const T *__restrict__ B, T *__restrict__ O,
+                                                 int64_t n, RowParams<T> p)
+{
+    constexpr int K = sym_k(N);
+    constexpr int ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? K : OP == SP_INVDIAG ? N : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t tile0 = (int64_t)blockIdx.x * 64;
+    const int64_t i = tile0 + threadIdx.x;
+    const bool live = i < n;
+    const int64_t ii = live ? i : n - 1; // lanes past the end redo the last matrix and store nothing
+    T m[K];
+    T v[OP == SP_SOLVE ? N : 1];
+    constexpr bool TILED = spd_tiled<T, N>();
+    using IM = TileIO<T, K, 64>;
+    using IV = TileIO<T, N, 64>;
+    using IR = TileIO<T, ROUT, 64>;
+    if constexpr (TILED) {
+        // the wavefront streams its 64 records with whole-line 16-byte accesses through an LDS image and every lane
+        // picks up its own (the vectors follow through the same bytes of LDS once the matrices are in registers)
+        typename IM::Stage sm;
+        typename IV::Stage sv;
+        IM::issue(A + tile0 * K, (n - tile0) * K, sm);
+        if constexpr (OP == SP_SOLVE) IV::issue(B + tile0 * N, (n - tile0) * N, sv);
+        IM::commit(reinterpret_cast<unsigned char *>(smem), sm);
+        __syncthreads();
+        IM::read_own(reinterpret_cast<const unsigned char *>(smem), m);
+        if constexpr (OP == SP_SOLVE) {
+            __syncthreads();
+            IV::commit(reinterpret_cast<unsigned char *>(smem), sv);
+            __syncthreads();
+            IV::read_own(reinterpret_cast<const unsigned char *>(smem), v);
+        }
+        if (!live) { // lanes past the end of the batch: the identity (positive definite: they do not trigger the fallback)
+#pragma unroll
+            for (int c = 0; c < K; ++c) m[c] = c < N ? T(1) : T(0);
+        }
+    } else {
+        load_record<T, K>(A + ii * K, m);
+        if constexpr (OP == SP_SOLVE) load_record<T, N>(B + ii * N, v);
+        __builtin_amdgcn_sched_barrier(0); // every load issued before the first use
+    }
+    if constexpr (OP == SP_SOLVE) {
+        if (p.has_eps) { // smoothing term on the diagonal (_impl/sym.py:356-357)
+#pragma unroll
+            for (int d = 0; d < N; ++d) m[d] += p.eps[d];
+        }
+    }
+    T det;
+    const bool ok = ldl_factor<T, N>(m, det);
+    if (__builtin_expect(!__any(!ok), 1)) {
+        // the result record of the lane: through the LDS image again (whole-line stores), or straight from the lane
+        auto put = [&](auto &rec) {
+            if constexpr (TILED) {
+                __syncthreads();
+                IR::write_own(reinterpret_cast<unsigned char *>(smem), rec);
+                __syncthreads();
+                IR::flush(O + tile0 * ROUT, (n - tile0) * ROUT, reinterpret_cast<const unsigned char *>(smem));
+            } else {
+                if (live) store_record<T, ROUT>(O + i * ROUT, rec);
+            }
+        };
+        if constexpr (OP == SP_SOLVE) {
+            T x[N];
+            ldl_solve<T, N>(m, v, x);
+            put(x);
+        } else if constexpr (OP == SP_DET) {
+            if (live) O[i] = det;
+        } else if constexpr (OP == SP_INV) {
+            ldl_inverse<T, N>(m);
+            put(m);
+        } else {
+            T dg[N];
+            ldl_inverse_diag<T, N>(m, dg);
+            put(dg);
+        }
+        return;
+    }
+    // not positive definite somewhere in this wavefront: nothing has been stored; the pivoted elimination of
+    // nfm_rowwave on this wavefront's 64 matrices, FR rows per lane = 4 FR matrices per pass (each pass reads its
+    // records before it writes: in-place calls are safe).  float32: 4 rows per lane, 4 passes; float64: one row
+    // per lane, 16 passes -- 4 rows of 16 doubles are 128 registers before anything else.
+    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR;
+#pragma unroll 1
+    for (int pass = 0; pass < 64 / FM; ++pass) {
+        const int64_t m0 = tile0 + FM * pass;
+        // (the lane id is made opaque per pass: everything a pass derives from it -- 64 LDS addresses and more --
+        // would otherwise be hoisted out of this loop and live, or spilled, across its body)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (m0 < n) roww::roww_tile<T, N, roww_op(OP), FR, false, FM>(A, B, O, n, m0, p, smem, tid);
+        __syncthreads();
+    }
+}
+
+template <typename T, int N, int OP>
+static int launch(const void *a, const void *b, void *o, int64_t n, const RowParams<T> &p, void *stream)
+{
+    constexpr size_t lds = spd_lds_bytes<T, N, OP>();
+    static_assert(lds <= 64 * 1024, "the fallback's tile must fit the default dynamic LDS limit");
+    if (n == 0) return NFM_OK;
+    const int64_t nblk = (n + 63) / 64;
+    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    hipLaunchKernelGGL((spd_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(64), lds, static_cast<hipStream_t>(stream),
+                       static_cast<const T *>(a), static_cast<const T *>(b), static_cast<T *>(o), n, p);
+    return launch_status();
+}
+
+template <typename T, int N>
+static int call(int op, int64_t n, const void *a, const void *b, void *o, const RowParams<T> &p, void *stream)
+{
+    switch (op) {
+    case SP_SOLVE: return launch<T, N, SP_SOLVE>(a, b, o, n, p, stream);
+    case SP_INV:
+        // float64 14..16: the record, a row of temporaries and the accumulators are past what the backend packs into
+        // 256 architectural registers + AGPR copies without scratch; those stay with the one-matrix-per-16-lanes kernels
+        if constexpr (sizeof(T) == 8 && N >= 14) return NFM_EFALLBACK_RW;
+        else return launch<T, N, SP_INV>(a, b, o, n, p, stream);
+    case SP_INVDIAG: return launch<T, N, SP_INVDIAG>(a, b, o, n, p, stream);
+    case SP_DET: return launch<T, N, SP_DET>(a, b, o, n, p, stream);
+    default: return NFM_EINVAL;
+    }
+}
+
+} // namespace spd
+
+#define NFM_SPD_F64 (NFM_SPD_PART / 4)
+#if NFM_SPD_PART % 4 == 0 // (a literal: it is pasted into the function's name)
+#define NFM_SPD_Q 0
+#elif NFM_SPD_PART % 4 == 1
+#define NFM_SPD_Q 1
+#elif NFM_SPD_PART % 4 == 2
+#define NFM_SPD_Q 2
+#else
+#define NFM_SPD_Q 3
+#endif
+#if NFM_SPD_F64
+using TS = double;
+#define NFM_SPD_NAME2(q) spd_call_f64_q##q
+#else
+using TS = float;
+#define NFM_SPD_NAME2(q) spd_call_f32_q##q
+#endif
+#define NFM_SPD_NAME1(q) NFM_SPD_NAME2(q)
+
+int NFM_SPD_NAME1(NFM_SPD_Q)(int op, int M, int64_t n, const void *a, const void *b, void *o, const double *eps, void *stream)
+{
+    spd::RowParams<TS> p;
+    p.has_eps = eps != nullptr;
+    for (int i = 0; i < NFM_MAX_DIM; ++i) p.eps[i] = (eps && i < M) ? (TS)eps[i] : TS(0);
+    if (M == 9 + 2 * NFM_SPD_Q) return spd::call<TS, 9 + 2 * NFM_SPD_Q>(op, n, a, b, o, p, stream);
+    if (M == 10 + 2 * NFM_SPD_Q) return spd::call<TS, 10 + 2 * NFM_SPD_Q>(op, n, a, b, o, p, stream);
+    return NFM_EFALLBACK_RW;
+}
+
+#if NFM_SPD_Q == 0
+// the front end lives in the q0 object of each dtype
+static bool spd_contig(const nfm_operand *o, int64_t rec, size_t elem)
+{
+    if (o == nullptr || o->ptr == nullptr) return false;
+    if (reinterpret_cast<uintptr_t>(o->ptr) % elem != 0) return false;
+    if (o->stride_inner != rec) return false;
+    if (rec > 1 && o->stride_col != 1) return false;
+    return true;
+}
+
+#if NFM_SPD_F64
+#define NFM_SPD_CALL(q) spd_call_f64_q##q
+#else
+#define NFM_SPD_CALL(q) spd_call_f32_q##q
+#endif
+static int spd_dispatch(int op, int M, int64_t n, const void *a, const void *b, void *o, const double *eps, void *stream)
+{
+    switch ((M - 9) >> 1) {
+    case 0: return NFM_SPD_CALL(0)(op, M, n, a, b, o, eps, stream);
+    case 1: return NFM_SPD_CALL(1)(op, M, n, a, b, o, eps, stream);
+    case 2: return NFM_SPD_CALL(2)(op, M, n, a, b, o, eps, stream);
+    case 3: return NFM_SPD_CALL(3)(op, M, n, a, b, o, eps, stream);
+    default: return NFM_EFALLBACK_RW;
+    }
+}
+
+template <>
+int Spd<TS>::sym_solve(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *vec, const nfm_operand *out,
+                       const double *eps, void *stream)
+{
+    const int K = M * (M + 1) / 2;
+    if (M < 9 || M > 16 || !spd_contig(mat, K, sizeof(TS)) || !spd_contig(vec, M, sizeof(TS)) ||
+        !spd_contig(out, M, sizeof(TS)))
+        return NFM_EFALLBACK_RW;
+    return spd_dispatch(SP_SOLVE, M, ni, mat->ptr, vec->ptr, out->ptr, eps, stream);
+}
+
+template <>
+int Spd<TS>::sym_invert(int M, int diag_only, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream)
+{
+    const int K = M * (M + 1) / 2;
+    if (M < 9 || M > 16 || !spd_contig(mat, K, sizeof(TS)) || !spd_contig(out, diag_only ? M : K, sizeof(TS)))
+        return NFM_EFALLBACK_RW;
+    return spd_dispatch(diag_only ? SP_INVDIAG : SP_INV, M, ni, mat->ptr, nullptr, out->ptr, nullptr, stream);
+}
+
+template <>
+int Spd<TS>::sym_det(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream)
+{
+    const int K = M * (M + 1) / 2;
+    if (M < 9 || M > 16 || !spd_contig(mat, K, sizeof(TS)) || out == nullptr || out->ptr == nullptr ||
+        out->stride_inner != 1)
+        return NFM_EFALLBACK_RW;
+    return spd_dispatch(SP_DET, M, ni, mat->ptr, nullptr, out->ptr, nullptr, stream);
+}
+#endif
+
+} // namespace nfm

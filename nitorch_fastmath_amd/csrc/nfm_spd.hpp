@@ -1,0 +1,26 @@
+// nfm_spd.hpp -- front end of the positive-definite-first kernels (nfm_spd.hip): orders 9..16 of sym_solve /
+// sym_invert / sym_det on contiguous compact records.  NFM_EFALLBACK_RW when the layout is not covered.
+#pragma once
+#include "nfm_common.hpp"
+#include "nfm_rowwave.hpp"
+
+namespace nfm {
+
+enum { SP_SOLVE = 0, SP_INV, SP_INVDIAG, SP_DET };
+
+// one object per (dtype, pair of orders): part = dtype * 4 + q holds orders 9 + 2 q and 10 + 2 q
+#define NFM_SPD_DECL(S, Q) \
+    int spd_call_##S##_q##Q(int op, int M, int64_t n, const void *a, const void *b, void *o, const double *eps, void *stream);
+NFM_SPD_DECL(f32, 0) NFM_SPD_DECL(f32, 1) NFM_SPD_DECL(f32, 2) NFM_SPD_DECL(f32, 3)
+NFM_SPD_DECL(f64, 0) NFM_SPD_DECL(f64, 1) NFM_SPD_DECL(f64, 2) NFM_SPD_DECL(f64, 3)
+#undef NFM_SPD_DECL
+
+template <typename T>
+struct Spd {
+    static int sym_solve(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *vec, const nfm_operand *out,
+                         const double *eps, void *stream);
+    static int sym_invert(int M, int diag_only, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream);
+    static int sym_det(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream);
+};
+
+} // namespace nfm

@@ -5,6 +5,7 @@
 #include "nfm_big.hpp"
 #include "nfm_large.hpp"
 #include "nfm_rowwave.hpp"
+#include "nfm_spd.hpp"
 
 namespace nfm {
 
@@ -385,6 +386,10 @@ static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operan
         return sym_bcast_big<T, BB_SOLVE>(M, kind, 0, no, ni, mat, vec, nullptr, out, p, stream);
     if (M > 8) {
         if (kind == NFM_MAT_SYM && no == 1) { // contiguous operands: registers; else LDS-resident
+            { // positive definite first, pivoted elimination for the wavefronts that need it (nfm_spd.hip)
+                const int rc = Spd<T>::sym_solve(M, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
+                if (rc != NFM_EFALLBACK) return rc;
+            }
             if (rowwave_first<T>(M, RWW_SOLVE)) { // one matrix per 16 lanes (nfm_rowwave.hip)
                 const int rc = RowWave<T>::sym_solve(M, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
                 if (rc != NFM_EFALLBACK) return rc;
@@ -453,6 +458,10 @@ static int sym_invert_t(int M, int diag_only, int64_t no, int64_t ni, const nfm_
                         const nfm_operand *out, void *stream)
 {
     if (M > 8) {
+        if (no == 1) { // positive definite first (nfm_spd.hip)
+            const int rc = Spd<T>::sym_invert(M, diag_only, ni, mat, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         if (no == 1 && rowwave_first<T>(M, diag_only ? RWW_INVDIAG_SYM : RWW_INV_SYM)) {
             const int rc = RowWave<T>::sym_invert(M, diag_only, ni, mat, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
@@ -476,6 +485,10 @@ template <typename T>
 static int sym_det_t(int M, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream)
 {
     if (M > 8) {
+        if (no == 1) { // positive definite first (nfm_spd.hip)
+            const int rc = Spd<T>::sym_det(M, ni, mat, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         if (no == 1 && rowwave_first<T>(M, RWW_DET_SYM)) {
             const int rc = RowWave<T>::sym_det(M, ni, mat, out, stream);
             if (rc != NFM_EFALLBACK) return rc;

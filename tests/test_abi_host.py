@@ -260,6 +260,9 @@ def test_no_scratch_anywhere():
     assert by['rec_kernel<float, SolveOp<float, 6, 0>, 1>']['vgpr'] <= 64
     assert by['rec_kernel<double, BatchInvOp<double, 8>, 1>']['vgpr'] <= 256       # 2 waves / SIMD
     rw = [k for k in rows if 'roww_kernel' in k['kernel']]
-    # (the 4-rows-per-lane float64 forms at order 16 -- measurement forms, never the dispatch table's choice --
-    # park one value in an accumulation register: 257)
-    assert rw and max(k['vgpr'] for k in rw) <= 260 and not any(k['scratch'] for k in rw)
+    # (the 4-rows-per-lane float64 forms at orders 14..16 -- measurement forms, never the dispatch table's choice --
+    # park up to 30 values in accumulation registers: 262..286)
+    assert rw and max(k['vgpr'] for k in rw) <= 300 and not any(k['scratch'] for k in rw)
+    # the positive-definite-first kernels (nfm_spd.hip): every (dtype, order, op) but the float64 inverses 14..16
+    sp = [k for k in rows if 'spd_kernel' in k['kernel']]
+    assert len(sp) == 2 * 8 * 4 - 3 and not any(k['scratch'] for k in sp)

@@ -236,3 +236,57 @@ def test_one_matrix_many_vectors_large_orders(dev, oracle, dn, M):
     # singular matrix: inf / nan like a division, no hang
     z = torch.zeros(1, one.shape[-1], dtype=vd.dtype, device=dev)
     assert not torch.isfinite(S.sym_solve(z, vd)).any()
+
+
+def sym_indefinite_np(n, M, dtype, seed, every):
+    """a positive definite batch in which every `every`-th matrix is made indefinite (a well
+    conditioned one: eigenvalues +-[1, 2], random orthogonal basis), compact storage"""
+    rng = np.random.default_rng(seed)
+    mat, vec = spd_np(n, M, np.float64, seed)
+    idx = np.arange(0, n, every)
+    Q, _ = np.linalg.qr(rng.standard_normal((len(idx), M, M)))
+    lam = rng.uniform(1, 2, (len(idx), M)) * np.where(rng.random((len(idx), M)) < 0.5, -1.0, 1.0)
+    lam[:, 0], lam[:, 1] = -np.abs(lam[:, 0]), np.abs(lam[:, 1])          # never definite
+    A = np.einsum('nij,nj,nkj->nik', Q, lam, Q)
+    iu = [(i, j) for i in range(M) for j in range(i + 1, M)]
+    c = np.concatenate([np.stack([A[:, i, i] for i in range(M)], -1), np.stack([A[:, i, j] for i, j in iu], -1)], -1)
+    mat[idx] = c
+    return mat.astype(dtype), vec.astype(dtype), idx
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', range(9, 17))
+def test_sym_large_orders_not_positive_definite(dev, oracle, dn, M):
+    """orders 9..16 try the unpivoted factorisation of positive definite matrices first (nfm_spd.hip) and
+    redo a wavefront with the pivoted elimination when ONE of its 64 matrices is not: batches with an
+    indefinite matrix in every wavefront, in some wavefronts, and a zero / a NaN matrix -- same answers as
+    the reference's LU (`_impl/sym.py:392-396`) for all of them, neighbours of the odd ones included"""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    S = N().sym
+    for n, every in ((1000 + M, 7), (1000 + M, 300), (3, 2), (64, 64), (65, 64)):
+        mat, vec, idx = sym_indefinite_np(n, M, dtype, 70 + M + every, every)
+        assert relerr(S.sym_solve(t(mat, dev), t(vec, dev)).cpu().numpy(), oracle.sym_solve(mat, vec)) <= 4 * TOL[dn]
+        assert relerr(S.sym_invert(t(mat, dev)).cpu().numpy(), oracle.sym_invert(mat)) <= 4 * TOL[dn]
+        assert relerr(S.sym_invert(t(mat, dev), diag=True).cpu().numpy(), oracle.sym_invert(mat, diag=True)) <= 4 * TOL[dn]
+        d, do = S.sym_det(t(mat, dev)).cpu().numpy().astype(np.float64), oracle.sym_det(mat).astype(np.float64)
+        assert np.abs(d / do - 1).max() <= 16 * TOL[dn]                  # every determinant, sign included
+        # in place: the wavefront that falls back has stored nothing before it does
+        v2 = t(vec, dev)
+        S.sym_solve_(t(mat, dev), v2)
+        assert relerr(v2.cpu().numpy(), oracle.sym_solve(mat, vec)) <= 4 * TOL[dn]
+        m2 = t(mat, dev)
+        S.sym_invert_(m2)
+        assert relerr(m2.cpu().numpy(), oracle.sym_invert(mat)) <= 4 * TOL[dn]
+        # eps on the diagonal goes through both paths
+        e = 0.25
+        assert relerr(S.sym_solve(t(mat, dev), t(vec, dev), eps=e).cpu().numpy(),
+                      oracle.sym_solve(mat + np.r_[np.full(M, e), np.zeros(M * (M - 1) // 2)].astype(dtype), vec)) <= 16 * TOL[dn]
+    # a singular and a NaN matrix among definite ones: inf / NaN for them, the neighbours untouched
+    mat, vec = spd_np(130, M, dtype, 5 + M)
+    ref = oracle.sym_solve(mat, vec)
+    mat[17] = 0
+    mat[99, 3] = np.nan
+    got = S.sym_solve(t(mat, dev), t(vec, dev)).cpu().numpy()
+    keep = np.ones(130, bool)
+    keep[[17, 99]] = False
+    assert relerr(got[keep], ref[keep]) <= TOL[dn] and not np.isfinite(got[17]).all() and np.isnan(got[99]).any()
