@@ -74,7 +74,10 @@ typedef struct nfm_operand {
  * implementation `_impl/sym.py:327-398`).  M <= 4: the reference's closed forms,
  * evaluated in its operation order (bit-identical to its CPU path); M > 4: LU with
  * partial pivoting of the full matrix in registers / LDS, like the
- * `torch.linalg.solve` branch (`_impl/sym.py:392-396`).  `eps` (NULL or M doubles on
+ * `torch.linalg.solve` branch (`_impl/sym.py:392-396`); contiguous operands at
+ * M = 9..16 (here, in nfm_sym_invert and in nfm_sym_det): the unpivoted LDL^T of the
+ * compact record first, the pivoted elimination for every wavefront that holds a matrix
+ * which is not positive definite -- same answers within rounding.  `eps` (NULL or M doubles on
  * the HOST) is added to the diagonal first (documented intent of `_impl/sym.py:356-357`).
  * `out` may alias `vec` (in-place variant). */
 int nfm_sym_solve(int dtype, int M, int mat_kind, int64_t n_outer, int64_t n_inner,
