@@ -6,6 +6,7 @@
 #include "nfm_big.hpp"
 #include "nfm_large.hpp"
 #include "nfm_rowwave.hpp"
+#include "nfm_spd.hpp"
 
 namespace nfm {
 
@@ -33,6 +34,10 @@ static int batch_inv_t(int N, int flags, int64_t no, int64_t ni, const nfm_opera
                        void *stream)
 {
     if (N > 8) {
+        if (no == 1) { // diagonal pivots first, the pivoted elimination for the wavefronts that need it (nfm_spd.hip)
+            const int rc = Spd<T>::batch_inv(N, ni, a, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         if (no == 1 && rowwave_first<T>(N, RWW_INV_GEN)) { // one matrix per 16 lanes (nfm_rowwave.hip)
             const int rc = RowWave<T>::batch_inv(N, ni, a, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
@@ -52,6 +57,10 @@ template <typename T>
 static int batch_det_t(int N, int64_t no, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
 {
     if (N > 8) {
+        if (no == 1) { // diagonal pivots first (nfm_spd.hip)
+            const int rc = Spd<T>::batch_det(N, ni, a, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         if (no == 1 && rowwave_first<T>(N, RWW_DET_GEN)) {
             const int rc = RowWave<T>::batch_det(N, ni, a, out, stream);
             if (rc != NFM_EFALLBACK) return rc;

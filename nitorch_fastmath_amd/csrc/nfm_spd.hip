@@ -28,6 +28,10 @@
 #ifndef NFM_SPD_PART
 #error "compile with -DNFM_SPD_PART=0..7"
 #endif
+#ifndef NFM_GEN_F64_MAX_INV
+#define NFM_GEN_F64_MAX_INV 11 // largest float64 orders of the general no-exchange kernels (N^2 doubles per lane + staging)
+#define NFM_GEN_F64_MAX_DET 11
+#endif
 
 namespace nfm {
 namespace spd {
@@ -37,7 +41,8 @@ using roww::RowParams;
 constexpr int roww_op(int op)
 {
     return op == SP_SOLVE ? roww::RW_SOLVE_SYM : op == SP_INV ? roww::RW_INV_SYM
-           : op == SP_INVDIAG ? roww::RW_INVDIAG_SYM : roww::RW_DET_SYM;
+           : op == SP_INVDIAG ? roww::RW_INVDIAG_SYM : op == SP_DET ? roww::RW_DET_SYM
+           : op == SP_GINV ? roww::RW_INV_GEN : roww::RW_DET_GEN;
 }
 
 // a lane's record <-> registers: element-aligned 16-byte accesses and a tail of single elements.  PLAIN accesses:
@@ -84,6 +89,162 @@ constexpr int spd_max_waves()
     return (sizeof(T) == 8 && N >= 14) ? 1 : 8;
 }
 
+// ---------------------------------------------------------------------------------------------
+// records <-> lanes through LDS images of 64 / S records (S = 1: the whole wavefront at once).  Whole-line 16-byte
+// accesses on the global side; the ragged last wavefront of a batch takes rolled element loops (an unrolled,
+// predicated ragged path -- TileIO's -- set the register count of these kernels: 292 instead of 183 at one point).
+template <typename T, int C, int S>
+struct SubOut {
+    static constexpr int L = 64 / S; // records per image
+    using G = TileIO<T, C, L>;       // geometry of the image: padded row stride, vector <-> byte offset
+    using V = typename VecOf<T>::type;
+    using VG = typename VecOf<T>::gtype;
+    static constexpr int kVec = VecOf<T>::N;
+    static constexpr size_t kLdsBytes = G::kLdsBytes;
+    // g: first record of the wavefront's 64; avail: elements that may be written from g on; `bad`: bit k set = the
+    // records 64 / NG * k .. of the wavefront are NOT to be written (their matrices go to the fallback, which must
+    // find its input untouched when the call is in place); group boundaries are multiples of 16 bytes
+    template <int NG>
+    static __device__ __forceinline__ void put(char *smem, const T (&r)[C], T *__restrict__ g, int64_t avail, int tid,
+                                               unsigned bad)
+    {
+        unsigned char *lds = reinterpret_cast<unsigned char *>(smem);
+        constexpr int GE = (64 / NG) * C; // elements of a group
+        static_assert(GE % kVec == 0, "a vector never straddles two groups");
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            __syncthreads();
+            if (tid / L == s) {
+                unsigned char *p = lds + (tid % L) * G::kRowStride;
+                if constexpr (G::kWide) {
+#pragma unroll
+                    for (int q = 0; q < G::kSlots; ++q) {
+                        V v;
+#pragma unroll
+                        for (int k = 0; k < kVec; ++k) v[k] = r[q * kVec + k];
+                        *reinterpret_cast<V *>(p + q * 16) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) *reinterpret_cast<T *>(p + c * sizeof(T)) = r[c];
+                }
+            }
+            __syncthreads();
+            T *gs = g + (int64_t)s * L * C;
+            const int64_t left = avail - (int64_t)s * L * C;
+            if (left >= (int64_t)L * C && bad == 0) { // uniform: nearly always
+#pragma unroll
+                for (int q = tid; q < G::kNVec; q += 64) {
+                    const V v = *reinterpret_cast<const V *>(lds + G::lds_off(q));
+                    NFM_STG(static_cast<VG>(v), reinterpret_cast<VG *>(gs) + q);
+                }
+            } else if (left > 0) { // the ragged last wavefront, or one with matrices for the fallback: a rolled loop
+#pragma unroll 1
+                for (int q = tid; q < G::kNVec; q += 64) {
+                    const int e0 = s * L * C + q * kVec; // element of the wavefront's block
+                    if ((bad >> (e0 / GE)) & 1u) continue;
+                    const V v = *reinterpret_cast<const V *>(lds + G::lds_off(q));
+#pragma unroll
+                    for (int k = 0; k < kVec; ++k)
+                        if ((int64_t)q * kVec + k < left) gs[(int64_t)q * kVec + k] = v[k];
+                }
+            }
+        }
+    }
+};
+
+// the way in: the wavefront's 64 records in S images of 64 / S.  EVERY load of all S images is issued first (C values
+// per lane in all -- the staging registers of image s are free once it is parked in LDS, the lanes of image s then
+// pick up their records: peak C + C (S - 1) / S registers), one round trip to memory.  Whole lines instead of a lane
+// walking its own record: at 16x16 float32 the records are 1 KiB apart, the 64 addresses of a lane-by-lane load
+// fall into the same cache sets and channel, and the general kernels ran at 0.33 of the roofline that way.
+template <typename T, int C, int S>
+struct SubIn {
+    static constexpr int L = 64 / S;
+    using G = TileIO<T, C, L>;
+    using V = typename VecOf<T>::type;
+    using VG = typename VecOf<T>::gtype;
+    static constexpr int kVec = VecOf<T>::N;
+    static constexpr int IT = (G::kNVec + 63) / 64;
+    static constexpr size_t kLdsBytes = G::kLdsBytes;
+    // this lane's record out of the image
+    static __device__ __forceinline__ void pick(const unsigned char *lds, T (&r)[C], int tid)
+    {
+        const unsigned char *p = lds + (tid % L) * G::kRowStride;
+        if constexpr (G::kWide) {
+#pragma unroll
+            for (int q = 0; q < G::kSlots; ++q) {
+                const V v = *reinterpret_cast<const V *>(p + q * 16);
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) r[q * kVec + k] = v[k];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) r[c] = *reinterpret_cast<const T *>(p + c * sizeof(T));
+        }
+    }
+    // a full wavefront: issue (every load of the S images, streaming loads, no waits) ... land (image by image)
+    struct Stage {
+        V v[S][IT];
+    };
+    static __device__ __forceinline__ void issue(Stage &st, const T *__restrict__ g, int tid)
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int q = tid + it * 64;
+                if (G::kNVec % 64 == 0 || q < G::kNVec)
+                    st.v[s][it] = NFM_LDG(reinterpret_cast<const VG *>(g + (int64_t)s * L * C) + q);
+            }
+    }
+    static __device__ __forceinline__ void land(char *smem, const Stage &st, T (&r)[C], int tid)
+    {
+        unsigned char *lds = reinterpret_cast<unsigned char *>(smem);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int q = tid + it * 64;
+                if (G::kNVec % 64 == 0 || q < G::kNVec) *reinterpret_cast<V *>(lds + G::lds_off(q)) = st.v[s][it];
+            }
+            __syncthreads();
+            if (tid / L == s) pick(lds, r, tid);
+        }
+    }
+    // the ragged last wavefront of a batch: element by element on a rolled loop, straight into the image (no staging
+    // registers: an unrolled, predicated version of this path set the register count of the kernel)
+    static __device__ __forceinline__ void get_ragged(char *smem, T (&r)[C], const T *__restrict__ g, int64_t avail, int tid)
+    {
+        unsigned char *lds = reinterpret_cast<unsigned char *>(smem);
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            const T *gs = g + (int64_t)s * L * C;
+            const int64_t left = avail - (int64_t)s * L * C;
+            __syncthreads();
+#pragma unroll 1
+            for (int e = tid; e < L * C; e += 64) {
+                const int rr = e / C, c = e - rr * C;
+                *reinterpret_cast<T *>(lds + rr * G::kRowStride + c * (int)sizeof(T)) = e < left ? gs[e] : T(0);
+            }
+            __syncthreads();
+            if (tid / L == s) pick(lds, r, tid);
+        }
+    }
+    static __device__ __forceinline__ void get(char *smem, T (&r)[C], const T *__restrict__ g, int64_t avail, int tid)
+    {
+        if (avail >= (int64_t)64 * C) { // uniform: every wavefront but the last
+            Stage st;
+            issue(st, g, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            land(smem, st, r, tid);
+        } else {
+            get_ragged(smem, r, g, avail, tid);
+        }
+    }
+};
+
 // how the records travel: through an LDS image of the wavefront's 64 records (whole-line accesses), or lane by lane
 // with element-aligned 16-byte accesses.  The image of float64 orders 13..16 is 46-70 KiB a wavefront -- two or
 // three wavefronts a CU -- so those go lane by lane (measured there: 0.60-0.65 of the roofline); everywhere else the
@@ -123,24 +284,21 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
     T m[K];
     T v[OP == SP_SOLVE ? N : 1];
     constexpr bool TILED = spd_tiled<T, N>();
-    using IM = TileIO<T, K, 64>;
-    using IV = TileIO<T, N, 64>;
-    using IR = TileIO<T, ROUT, 64>;
     if constexpr (TILED) {
         // the wavefront streams its 64 records with whole-line 16-byte accesses through an LDS image and every lane
         // picks up its own (the vectors follow through the same bytes of LDS once the matrices are in registers)
-        typename IM::Stage sm;
-        typename IV::Stage sv;
-        IM::issue(A + tile0 * K, (n - tile0) * K, sm);
-        if constexpr (OP == SP_SOLVE) IV::issue(B + tile0 * N, (n - tile0) * N, sv);
-        IM::commit(reinterpret_cast<unsigned char *>(smem), sm);
-        __syncthreads();
-        IM::read_own(reinterpret_cast<const unsigned char *>(smem), m);
-        if constexpr (OP == SP_SOLVE) {
-            __syncthreads();
-            IV::commit(reinterpret_cast<unsigned char *>(smem), sv);
-            __syncthreads();
-            IV::read_own(reinterpret_cast<const unsigned char *>(smem), v);
+        using IM = SubIn<T, K, 1>;
+        using IV = SubIn<T, N, 1>;
+        if (n - tile0 >= 64) { // uniform: every wavefront but the last
+            typename IM::Stage sm;
+            typename IV::Stage sv;
+            IM::issue(sm, A + tile0 * K, (int)threadIdx.x);
+            if constexpr (OP == SP_SOLVE) IV::issue(sv, B + tile0 * N, (int)threadIdx.x);
+            IM::land(smem, sm, m, (int)threadIdx.x);
+            if constexpr (OP == SP_SOLVE) IV::land(smem, sv, v, (int)threadIdx.x);
+        } else {
+            IM::get_ragged(smem, m, A + tile0 * K, (n - tile0) * K, (int)threadIdx.x);
+            if constexpr (OP == SP_SOLVE) IV::get_ragged(smem, v, B + tile0 * N, (n - tile0) * N, (int)threadIdx.x);
         }
         if (!live) { // lanes past the end of the batch: the identity (positive definite: they do not trigger the fallback)
 #pragma unroll
@@ -159,16 +317,24 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
     }
     T det;
     const bool ok = ldl_factor<T, N>(m, det);
-    if (__builtin_expect(!__any(!ok), 1)) {
+    // the vote.  Matrices go to the fallback in groups of FM = what one of its passes works on; every other lane of
+    // the wavefront finishes and stores as if nothing had happened (the groups of the bad matrices store nothing: an
+    // in-place call must leave their input for the fallback)
+    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR, NG = 64 / FM;
+    const unsigned long long badl = __ballot(!ok);
+    unsigned bad = 0;
+    if (__builtin_expect(badl != 0, 0)) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) bad |= ((badl >> (k * FM)) & ((1ull << FM) - 1ull)) ? (1u << k) : 0u;
+    }
+    const bool mine = live && !((bad >> (threadIdx.x / FM)) & 1u); // this lane's result is stored by this path
+    {
         // the result record of the lane: through the LDS image again (whole-line stores), or straight from the lane
         auto put = [&](auto &rec) {
             if constexpr (TILED) {
-                __syncthreads();
-                IR::write_own(reinterpret_cast<unsigned char *>(smem), rec);
-                __syncthreads();
-                IR::flush(O + tile0 * ROUT, (n - tile0) * ROUT, reinterpret_cast<const unsigned char *>(smem));
+                SubOut<T, ROUT, 1>::template put<NG>(smem, rec, O + tile0 * ROUT, (n - tile0) * ROUT, (int)threadIdx.x, bad);
             } else {
-                if (live) store_record<T, ROUT>(O + i * ROUT, rec);
+                if (mine) store_record<T, ROUT>(O + i * ROUT, rec);
             }
         };
         if constexpr (OP == SP_SOLVE) {
@@ -176,7 +342,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
             ldl_solve<T, N>(m, v, x);
             put(x);
         } else if constexpr (OP == SP_DET) {
-            if (live) O[i] = det;
+            if (mine) O[i] = det;
         } else if constexpr (OP == SP_INV) {
             ldl_inverse<T, N>(m);
             put(m);
@@ -185,23 +351,125 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
             ldl_inverse_diag<T, N>(m, dg);
             put(dg);
         }
-        return;
     }
-    // not positive definite somewhere in this wavefront: nothing has been stored; the pivoted elimination of
-    // nfm_rowwave on this wavefront's 64 matrices, FR rows per lane = 4 FR matrices per pass (each pass reads its
-    // records before it writes: in-place calls are safe).  float32: 4 rows per lane, 4 passes; float64: one row
-    // per lane, 16 passes -- 4 rows of 16 doubles are 128 registers before anything else.
-    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR;
+    if (__builtin_expect(bad == 0, 1)) return;
+    // not positive definite somewhere in this wavefront: the pivoted elimination of nfm_rowwave on the groups that
+    // hold such a matrix, FR rows per lane = FM matrices per pass (a pass reads its records before it writes: in-place
+    // calls are safe).  float32: 4 rows per lane, up to 4 passes; float64: one row per lane, up to 16 passes -- 4 rows
+    // of 16 doubles are 128 registers before anything else.
 #pragma unroll 1
-    for (int pass = 0; pass < 64 / FM; ++pass) {
+    for (int pass = 0; pass < NG; ++pass) {
         const int64_t m0 = tile0 + FM * pass;
         // (the lane id is made opaque per pass: everything a pass derives from it -- 64 LDS addresses and more --
         // would otherwise be hoisted out of this loop and live, or spilled, across its body)
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
-        if (m0 < n) roww::roww_tile<T, N, roww_op(OP), FR, false, FM>(A, B, O, n, m0, p, smem, tid);
+        if (((bad >> pass) & 1u) && m0 < n) roww::roww_tile<T, N, roww_op(OP), FR, false, FM>(A, B, O, n, m0, p, smem, tid);
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batchinv / batchdet of GENERAL matrices at orders 9..16: DIAGONAL PIVOTS FIRST (nfm_smallmat.hpp:
+// gj_inverse_nopivot / lu_det_nopivot).  Same frame as above: one matrix per lane on N^2 registers, the elimination
+// without row exchanges accepts the diagonal while it is within a factor 8 of the column maximum, the wavefront votes,
+// and a wavefront with one matrix that needed an exchange redoes its 64 matrices with the pivoted row-wave kernels.
+// A record is N^2 values (1 KiB at 16x16 float32): the image of 64 of them does not fit next to three other
+// wavefronts, so the records come and go through LDS images of 64 / S of them at a time (SubIn / SubOut: whole-line
+// accesses both ways).
+// images per wavefront for the output of the general inverse: the smallest S whose image stays under 40 KiB
+template <typename T, int N>
+constexpr int gen_out_subs()
+{
+    return TileIO<T, N * N, 64>::kLdsBytes <= 40 * 1024 ? 1 : TileIO<T, N * N, 32>::kLdsBytes <= 40 * 1024 ? 2 : 4;
+}
+// float64 from order 12 up holds more than 256 values per lane: one wavefront per SIMD (see spd_max_waves)
+template <typename T, int N>
+constexpr int gen_max_waves()
+{
+    return (sizeof(T) == 8 && N >= 10) ? 1 : 8;
+}
+template <typename T, int N, int OP>
+constexpr size_t gen_lds_bytes()
+{
+    size_t b = roww::tile_lds_bytes<T, N, roww_op(OP), false, (sizeof(T) == 8 ? 4 : 16)>();
+    const size_t t = SubOut<T, N * N, gen_out_subs<T, N>()>::kLdsBytes; // (the way in uses the same geometry)
+    b = b > t ? b : t;
+    return b;
+}
+
+template <typename T, int N, int OP>
+__global__ __attribute__((amdgpu_waves_per_eu(1, gen_max_waves<T, N>()))) __launch_bounds__(64) void gen_kernel(
+    const T *__restrict__ A, T *__restrict__ O, int64_t n, RowParams<T> p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t tile0 = (int64_t)blockIdx.x * 64;
+    const int64_t i = tile0 + threadIdx.x;
+    const bool live = i < n;
+    T f[N * N];
+    SubIn<T, N * N, gen_out_subs<T, N>()>::get(smem, f, A + tile0 * (N * N), (n - tile0) * (N * N), (int)threadIdx.x);
+    if (!live) { // lanes past the end of the batch: the identity (they do not trigger the fallback)
+#pragma unroll
+        for (int c = 0; c < N * N; ++c) f[c] = (c % (N + 1) == 0) ? T(1) : T(0);
+    }
+    T a[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = 0; c < N; ++c) a[r][c] = f[r * N + c];
+    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR, NG = 64 / FM;
+    bool ok;
+    T det = T(0);
+    if constexpr (OP == SP_GDET) det = lu_det_nopivot<T, N>(a, ok);
+    else gj_inverse_nopivot<T, N>(a, ok);
+    // the vote: see spd_kernel
+    const unsigned long long badl = __ballot(!ok);
+    unsigned bad = 0;
+    if (__builtin_expect(badl != 0, 0)) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) bad |= ((badl >> (k * FM)) & ((1ull << FM) - 1ull)) ? (1u << k) : 0u;
+    }
+    if constexpr (OP == SP_GDET) {
+        if (live && !((bad >> (threadIdx.x / FM)) & 1u)) O[i] = det;
+    } else {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c < N; ++c) f[r * N + c] = a[r][c];
+        SubOut<T, N * N, gen_out_subs<T, N>()>::template put<NG>(smem, f, O + tile0 * (N * N), (n - tile0) * (N * N),
+                                                                 (int)threadIdx.x, bad);
+    }
+    if (__builtin_expect(bad == 0, 1)) return;
+    // a row exchange was needed somewhere in this wavefront: the pivoted elimination on the groups that hold such a matrix
+#pragma unroll 1
+    for (int pass = 0; pass < NG; ++pass) {
+        const int64_t m0 = tile0 + FM * pass;
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid)); // (see spd_kernel)
+        if (((bad >> pass) & 1u) && m0 < n) roww::roww_tile<T, N, roww_op(OP), FR, false, FM>(A, nullptr, O, n, m0, p, smem, tid);
+        __syncthreads();
+    }
+}
+
+template <typename T, int N, int OP>
+static int launch_gen(const void *a, void *o, int64_t n, void *stream)
+{
+    constexpr size_t lds = gen_lds_bytes<T, N, OP>();
+    static_assert(lds <= 64 * 1024, "the images must fit the default dynamic LDS limit");
+    if (n == 0) return NFM_OK;
+    const int64_t nblk = (n + 63) / 64;
+    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    RowParams<T> p{};
+    hipLaunchKernelGGL((gen_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(64), lds, static_cast<hipStream_t>(stream),
+                       static_cast<const T *>(a), static_cast<T *>(o), n, p);
+    return launch_status();
+}
+
+// the orders whose N^2 record (+ temporaries) the backend holds in a lane without scratch (scripts/survey_spd.sh)
+template <typename T, int N, int OP>
+constexpr bool gen_fits()
+{
+    return sizeof(T) == 4 || N <= (OP == SP_GINV ? NFM_GEN_F64_MAX_INV : NFM_GEN_F64_MAX_DET);
 }
 
 template <typename T, int N, int OP>
@@ -229,6 +497,12 @@ static int call(int op, int64_t n, const void *a, const void *b, void *o, const 
         else return launch<T, N, SP_INV>(a, b, o, n, p, stream);
     case SP_INVDIAG: return launch<T, N, SP_INVDIAG>(a, b, o, n, p, stream);
     case SP_DET: return launch<T, N, SP_DET>(a, b, o, n, p, stream);
+    case SP_GINV:
+        if constexpr (gen_fits<T, N, SP_GINV>()) return launch_gen<T, N, SP_GINV>(a, o, n, stream);
+        else return NFM_EFALLBACK_RW;
+    case SP_GDET:
+        if constexpr (gen_fits<T, N, SP_GDET>()) return launch_gen<T, N, SP_GDET>(a, o, n, stream);
+        else return NFM_EFALLBACK_RW;
     default: return NFM_EINVAL;
     }
 }
@@ -282,6 +556,10 @@ static bool spd_contig(const nfm_operand *o, int64_t rec, size_t elem)
 #endif
 static int spd_dispatch(int op, int M, int64_t n, const void *a, const void *b, void *o, const double *eps, void *stream)
 {
+    // measurement knob (only under NFM_DEBUG, like the row-wave ones): NFM_SPD_OFF=1 sends everything to the pivoted
+    // kernels, NFM_SPD_OFF=2 only the general matrices -- the A/B runs of scripts/bench_spd_ab.py
+    static const int off = [] { const char *e = roww::dbg_env("NFM_SPD_OFF"); return e ? atoi(e) : 0; }();
+    if (off == 1 || (off == 2 && (op == SP_GINV || op == SP_GDET))) return NFM_EFALLBACK_RW;
     switch ((M - 9) >> 1) {
     case 0: return NFM_SPD_CALL(0)(op, M, n, a, b, o, eps, stream);
     case 1: return NFM_SPD_CALL(1)(op, M, n, a, b, o, eps, stream);
@@ -309,6 +587,25 @@ int Spd<TS>::sym_invert(int M, int diag_only, int64_t ni, const nfm_operand *mat
     if (M < 9 || M > 16 || !spd_contig(mat, K, sizeof(TS)) || !spd_contig(out, diag_only ? M : K, sizeof(TS)))
         return NFM_EFALLBACK_RW;
     return spd_dispatch(diag_only ? SP_INVDIAG : SP_INV, M, ni, mat->ptr, nullptr, out->ptr, nullptr, stream);
+}
+
+template <>
+int Spd<TS>::batch_inv(int Nn, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
+{
+    const int64_t rec = (int64_t)Nn * Nn;
+    auto full = [&](const nfm_operand *o) { return spd_contig(o, rec, sizeof(TS)) && o->stride_row == Nn; };
+    if (Nn < 9 || Nn > 16 || !full(a) || !full(out)) return NFM_EFALLBACK_RW;
+    return spd_dispatch(SP_GINV, Nn, ni, a->ptr, nullptr, out->ptr, nullptr, stream);
+}
+
+template <>
+int Spd<TS>::batch_det(int Nn, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream)
+{
+    const int64_t rec = (int64_t)Nn * Nn;
+    if (Nn < 9 || Nn > 16 || !spd_contig(a, rec, sizeof(TS)) || a->stride_row != Nn || out == nullptr ||
+        out->ptr == nullptr || out->stride_inner != 1)
+        return NFM_EFALLBACK_RW;
+    return spd_dispatch(SP_GDET, Nn, ni, a->ptr, nullptr, out->ptr, nullptr, stream);
 }
 
 template <>

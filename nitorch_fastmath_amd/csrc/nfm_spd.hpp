@@ -1,12 +1,13 @@
-// nfm_spd.hpp -- front end of the positive-definite-first kernels (nfm_spd.hip): orders 9..16 of sym_solve /
-// sym_invert / sym_det on contiguous compact records.  NFM_EFALLBACK_RW when the layout is not covered.
+// nfm_spd.hpp -- front end of the no-exchange-first kernels (nfm_spd.hip): orders 9..16 of sym_solve / sym_invert /
+// sym_det on contiguous compact records (positive definite first) and of batchinv / batchdet on contiguous
+// row-major matrices (diagonal pivots first).  NFM_EFALLBACK_RW when the layout is not covered.
 #pragma once
 #include "nfm_common.hpp"
 #include "nfm_rowwave.hpp"
 
 namespace nfm {
 
-enum { SP_SOLVE = 0, SP_INV, SP_INVDIAG, SP_DET };
+enum { SP_SOLVE = 0, SP_INV, SP_INVDIAG, SP_DET, SP_GINV, SP_GDET }; // G*: general (full, row-major) matrices
 
 // one object per (dtype, pair of orders): part = dtype * 4 + q holds orders 9 + 2 q and 10 + 2 q
 #define NFM_SPD_DECL(S, Q) \
@@ -21,6 +22,8 @@ struct Spd {
                          const double *eps, void *stream);
     static int sym_invert(int M, int diag_only, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream);
     static int sym_det(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream);
+    static int batch_inv(int N, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream);
+    static int batch_det(int N, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream);
 };
 
 } // namespace nfm

@@ -290,3 +290,42 @@ def test_sym_large_orders_not_positive_definite(dev, oracle, dn, M):
     keep = np.ones(130, bool)
     keep[[17, 99]] = False
     assert relerr(got[keep], ref[keep]) <= TOL[dn] and not np.isfinite(got[17]).all() and np.isnan(got[99]).any()
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('n', range(9, 17))
+def test_general_large_orders_diagonal_pivots_first(dev, oracle, dn, n):
+    """`batchinv` / `batchdet` at orders 9..16 try the elimination WITHOUT row exchanges first (the diagonal is
+    accepted while it is within a factor 8 of its column's maximum: nfm_spd.hip) and redo a wavefront with the
+    pivoted elimination when one of its 64 matrices needed an exchange.  `test_general_large_orders` has such a
+    matrix in every wavefront; here: none at all (the no-exchange path alone), one every 300 (both paths in one
+    launch), a permuted identity-like batch (every matrix needs exchanges), ragged sizes -- against the oracle's
+    pivoted LU (`_impl/batched.py:119-120`, `:53-54`) at TOL, and A A^-1 = I."""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    B = N().batched
+    rng = np.random.default_rng(170 + n)
+    for nb, every in ((1500 + n, 0), (1500 + n, 300), (1, 0), (63, 0), (65, 64)):
+        a = (rng.standard_normal((nb, n, n)) + 8 * np.eye(n)).astype(dtype)
+        if every:
+            a[::every] = a[::every][:, ::-1]          # rows reversed: the diagonal is the wrong pivot everywhere
+        inv = B.batchinv(t(a, dev)).cpu().numpy()
+        assert relerr(inv, oracle.batch_inv(a)) <= 4 * TOL[dn]
+        eye = np.einsum('bij,bjk->bik', a.astype(np.float64), inv.astype(np.float64))
+        assert np.abs(eye - np.eye(n)).max() <= 64 * n * EPS[dn]
+        d, do = B.batchdet(t(a, dev)).cpu().numpy().astype(np.float64), oracle.batch_det(a).astype(np.float64)
+        assert np.abs(d / do - 1).max() <= 16 * TOL[dn]              # every determinant, sign included
+    # a diagonal that is acceptable at first and not later (the test is made at every step)
+    a = (rng.standard_normal((200, n, n)) * 0.1 + np.eye(n)).astype(dtype)
+    a[::3, n - 1, n - 1] = 0
+    a[::3, n - 1, n - 2] = 1
+    assert relerr(B.batchinv(t(a, dev)).cpu().numpy(), oracle.batch_inv(a)) <= 64 * TOL[dn]
+    # singular and NaN matrices among good ones: inf / NaN for them only
+    a = (rng.standard_normal((130, n, n)) + 8 * np.eye(n)).astype(dtype)
+    ref = oracle.batch_inv(a)
+    a[17] = 0
+    a[99, 3, 3] = np.nan
+    got = B.batchinv(t(a, dev)).cpu().numpy()
+    keep = np.ones(130, bool)
+    keep[[17, 99]] = False
+    assert relerr(got[keep], ref[keep]) <= TOL[dn] and not np.isfinite(got[17]).all() and np.isnan(got[99]).any()
+    assert B.batchdet(t(a, dev)).cpu().numpy()[17] == 0
