@@ -61,6 +61,10 @@ if has tables; then
   timeout -k 10 400 python scripts/bench_layouts.py > $O/layouts_table_${TAG}.md 2>/dev/null; echo "layouts rc=$?"
   timeout -k 10 400 python scripts/bench_median.py > $O/median_table_${TAG}.md 2>/dev/null; echo "median rc=$?"
   timeout -k 10 300 python scripts/bench_latency.py > $O/latency_table_${TAG}.md 2>/dev/null; echo "latency rc=$?"
+  # no-exchange-first kernels of orders 9..16 against the pivoted kernels behind them, same box, same inputs
+  timeout -k 10 300 python scripts/bench_spd_ab.py 2>/dev/null > $O/spd_ab_${TAG}_first.md; echo "spd ab (first) rc=$?"
+  NFM_DEBUG=1 NFM_SPD_OFF=1 timeout -k 10 300 python scripts/bench_spd_ab.py 2>/dev/null > $O/spd_ab_${TAG}_pivoted.md; echo "spd ab (pivoted) rc=$?"
+  NFM_DEBUG=1 NFM_SPD_OFF=1 ORDERS_SYM=9,12,16 ORDERS_GEN=9,12,16 timeout -k 10 400 python scripts/bench_table.py 2>/dev/null > $O/throughput_table_${TAG}_pivoted.md; echo "throughput (pivoted arm) rc=$?"
 fi
 if has fuzz; then
   timeout -k 10 400 python scripts/fuzz_gpu.py 150 51 > $O/fuzz_gpu_${TAG}.log 2>&1; echo "fuzz_gpu rc=$?"; tail -2 $O/fuzz_gpu_${TAG}.log
