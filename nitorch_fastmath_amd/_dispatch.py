@@ -136,9 +136,13 @@ class Batch:
     def __init__(self, batch_shape, tensors, ncomp, _copyback=None, pack=False):
         # tensors[k] has shape batch_shape + comp dims (ncomp[k] trailing dims), already
         # expanded; the LAST tensor is the output.
-        # pack=True (orders 9..16): the register kernels of those orders only take batch-major
-        # contiguous records, and one packing copy (2x the operand's bytes at ~5 TB/s) is far
-        # cheaper than the LDS-resident strided fallback; broadcast operands are left alone.
+        # pack=True (orders 9..16): the fast kernels of those orders want records back to back (or, since
+        # round 3, component-major fields: `spd_strided_kernel` addresses any strides, and with the batch
+        # running along memory its lanes read consecutive addresses).  Records that are strided ALONG the batch
+        # (every other record, padded records, component stride 2) would be fetched lane by lane, 4 bytes at a
+        # time, a record apart: measured 0.9-1.4 TB/s against 1.8-2.3 for one packing copy (2x the operand's
+        # bytes at ~5 TB/s) + the fast kernel, so those are still packed; broadcast and component-major
+        # operands are left alone (pack='all': component-major ones too, for the ops without such a kernel).
         nb = len(batch_shape)
         self.shape = tuple(batch_shape)
         self._copyback = _copyback
@@ -163,7 +167,7 @@ class Batch:
                     self.operands.append(_lib.Operand(t.data_ptr(), 0, rec if numel > 1 else 0, sr, sc))
                 return
         if pack:
-            tensors = self._pack(tensors, nb)
+            tensors = self._pack(tensors, nb, keep_soa=(pack != 'all'))
         strides = [list(t.stride()[:nb]) for t in tensors]
         sizes, per_op = _collapse(self.shape, strides)
         if len(sizes) > 2:
@@ -206,11 +210,13 @@ class Batch:
             self.operands.append(_lib.Operand(t.data_ptr(), so, si, sr, sc))
 
 
-    def _pack(self, tensors, nb):
+    def _pack(self, tensors, nb, keep_soa=True):
         new = []
         for k, t in enumerate(tensors):
             bcast = any(st == 0 and sz > 1 for st, sz in zip(t.stride()[:nb], t.shape[:nb]))
-            if bcast or t.is_contiguous() or t.numel() == 0:
+            # component-major (channel-first) field: the innermost batch dim runs along memory
+            soa = keep_soa and nb > 0 and t.dim() > nb and t.stride(nb - 1) == 1 and t.stride(nb) != 1
+            if bcast or soa or t.is_contiguous() or t.numel() == 0:
                 new.append(t)
                 continue
             c = t.contiguous()

@@ -29,6 +29,12 @@ struct RowParams {
     T eps[NFM_MAX_DIM];
 };
 
+// element strides of the operands of a STRIDED tile (the fallback of the strided kernels of nfm_spd.hip; compact
+// symmetric ops only): element c of matrix m at ptr[m * si + c * sc]
+struct RowStrides {
+    int64_t a_si, a_sc, b_si, b_sc, o_si, o_sc;
+};
+
 // row stride of the N x N LDS image in elements: a whole, odd number of 16-byte slots
 template <typename T, int N>
 struct RowStride {
@@ -143,9 +149,10 @@ __device__ __forceinline__ unsigned groupmax(unsigned v)
 // workgroup (all of them call it, `tid` = threadIdx.x); `smem`: img_elems + (LB ? MPB * NS : 0) elements of LDS.  The kernel below is
 // this function on tile blockIdx.x; the positive-definite-first kernels of nfm_spd.hip call it (R = 4: one
 // wavefront) for the wavefronts that met a matrix their unpivoted factorisation does not cover.
-template <typename T, int N, int OP, int R, bool LB, int MPB_ = MPB>
+template <typename T, int N, int OP, int R, bool LB, int MPB_ = MPB, bool STR = false>
 __device__ __forceinline__ void roww_tile(const T *__restrict__ A, const T *__restrict__ B, T *__restrict__ O, int64_t n,
-                                          int64_t m0, const RowParams<T> &p, char *smem, const int tid)
+                                          int64_t m0, const RowParams<T> &p, char *smem, const int tid,
+                                          const RowStrides &st = RowStrides{})
 {
     constexpr bool SYM = OP == RW_SOLVE_SYM || OP == RW_INV_SYM || OP == RW_INVDIAG_SYM || OP == RW_DET_SYM;
     constexpr bool INV = OP == RW_INV_SYM || OP == RW_INVDIAG_SYM || OP == RW_INV_GEN;
@@ -168,8 +175,15 @@ __device__ __forceinline__ void roww_tile(const T *__restrict__ A, const T *__re
     const unsigned gmask = (1u << G) - 1u;
     const int nm = (int)((n - m0) < MPB_ ? (n - m0) : MPB_);
 
-    // ---- stream the tile's contiguous input records into LDS
-    {
+    // ---- stream the tile's contiguous input records into LDS (strided operands: element by element)
+    if constexpr (STR) {
+        static_assert(!STR || SYM, "strided tiles: compact symmetric ops only");
+        const int total = nm * RIN;
+        for (int e = tid; e < total; e += NT) {
+            const int m = e / RIN, c = e - m * RIN;
+            img[e] = A[(m0 + m) * st.a_si + c * st.a_sc];
+        }
+    } else {
         const T *src = A + m0 * RIN;
         const int total = nm * RIN;
         // a tile starts a whole number of 16-matrix blocks into the operand: 16-byte aligned exactly
@@ -224,7 +238,10 @@ __device__ __forceinline__ void roww_tile(const T *__restrict__ A, const T *__re
             for (int j = 0; j < N; ++j) row[t][j] = live ? img[(g * N + rid) * RS + j] : T(0);
         }
         rhs[t] = T(0);
-        if constexpr (OP == RW_SOLVE_SYM) rhs[t] = live ? NFM_LDG(B + (m0 + g) * N + rid) : T(0);
+        if constexpr (OP == RW_SOLVE_SYM) {
+            if constexpr (STR) rhs[t] = live ? B[(m0 + g) * st.b_si + rid * st.b_sc] : T(0);
+            else rhs[t] = live ? NFM_LDG(B + (m0 + g) * N + rid) : T(0);
+        }
         used[t] = !(rid < N); // rows beyond the order never pivot
         if (!(g < nm)) {      // idle matrices of a ragged last tile: the identity (nothing divides by zero)
 #pragma unroll
@@ -351,11 +368,17 @@ __device__ __forceinline__ void roww_tile(const T *__restrict__ A, const T *__re
             T piv = T(1); // the pivot is still at column ppos of the row
 #pragma unroll
             for (int j = 0; j < N; ++j) piv = (ppos[t] == j) ? row[t][j] : piv;
-            if (g < nm && ppos[t] >= 0) NFM_STG(rhs[t] / piv, O + (m0 + g) * N + ppos[t]);
+            if (g < nm && ppos[t] >= 0) {
+                if constexpr (STR) O[(m0 + g) * st.o_si + ppos[t] * st.o_sc] = rhs[t] / piv;
+                else NFM_STG(rhs[t] / piv, O + (m0 + g) * N + ppos[t]);
+            }
         }
     } else if constexpr (DET) {
         const T d = (inversions & 1) ? -det : det;
-        if (lr == 0 && g < nm) NFM_STG(d, O + (m0 + g));
+        if (lr == 0 && g < nm) {
+            if constexpr (STR) O[(m0 + g) * st.o_si] = d;
+            else NFM_STG(d, O + (m0 + g));
+        }
     } else {
         // its l-th value is column col_of[l]
         __syncthreads(); // everyone is done reading the input image
@@ -380,6 +403,13 @@ __device__ __forceinline__ void roww_tile(const T *__restrict__ A, const T *__re
         __syncthreads();
         T *dst = O + m0 * ROUT;
         const int total = nm * ROUT;
+        if constexpr (STR) {
+            for (int e = tid; e < total; e += NT) {
+                const int m = e / ROUT, c = e - m * ROUT;
+                O[(m0 + m) * st.o_si + c * st.o_sc] = img[e];
+            }
+            return;
+        }
         const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
         for (int e = tid * V; e < total; e += NT * V) {
             T tmp[V];

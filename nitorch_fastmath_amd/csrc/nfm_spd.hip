@@ -370,6 +370,126 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
 }
 
 // ---------------------------------------------------------------------------------------------
+// the same kernel for ANY element strides of the compact operands and a second batch level (blockIdx.y):
+// channel-first fields -- component c of matrix i at ptr[c * plane + i]: what the callers of these functions hold,
+// and for a lane-per-matrix kernel the ideal layout, consecutive lanes read consecutive addresses --, padded or
+// interleaved records, one vector for every matrix (stride 0).  Every lane addresses its own record element by
+// element; the fallback gathers its group's records into the LDS image of nfm_rowwave and scatters the results
+// (`roww_tile<..., STR = true>`).  Before this kernel these layouts went to the LDS-resident kernels of nfm_big.hpp
+// (0.2-0.9 TB/s at orders 12 and 16) or through the facade's packing copy.
+struct SOp {
+    const void *ptr;
+    int64_t so, si, sc; // element strides: outer batch level, inner batch level, component
+};
+
+template <typename T, int N, int OP>
+__global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __launch_bounds__(64) void spd_strided_kernel(
+    SOp a, SOp b, SOp o, int64_t n, RowParams<T> p)
+{
+    constexpr int K = sym_k(N);
+    constexpr int ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? K : OP == SP_INVDIAG ? N : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const T *A = static_cast<const T *>(a.ptr) + (int64_t)blockIdx.y * a.so;
+    const T *B = OP == SP_SOLVE ? static_cast<const T *>(b.ptr) + (int64_t)blockIdx.y * b.so : nullptr;
+    T *O = const_cast<T *>(static_cast<const T *>(o.ptr)) + (int64_t)blockIdx.y * o.so;
+    const int64_t tile0 = (int64_t)blockIdx.x * 64;
+    const int64_t i = tile0 + threadIdx.x;
+    const bool live = i < n;
+    const int64_t ii = live ? i : n - 1; // lanes past the end redo the last matrix and store nothing
+    T m[K];
+    T v[OP == SP_SOLVE ? N : 1];
+    {
+        const T *pa = A + ii * a.si;
+#pragma unroll
+        for (int c = 0; c < K; ++c) m[c] = pa[c * a.sc];
+        if constexpr (OP == SP_SOLVE) {
+            const T *pb = B + ii * b.si;
+#pragma unroll
+            for (int c = 0; c < N; ++c) v[c] = pb[c * b.sc];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0); // every load issued before the first use
+    if constexpr (OP == SP_SOLVE) {
+        if (p.has_eps) {
+#pragma unroll
+            for (int d = 0; d < N; ++d) m[d] += p.eps[d];
+        }
+    }
+    T det;
+    const bool ok = ldl_factor<T, N>(m, det);
+    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR, NG = 64 / FM;
+    const unsigned long long badl = __ballot(!ok);
+    unsigned bad = 0;
+    if (__builtin_expect(badl != 0, 0)) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) bad |= ((badl >> (k * FM)) & ((1ull << FM) - 1ull)) ? (1u << k) : 0u;
+    }
+    const bool mine = live && !((bad >> (threadIdx.x / FM)) & 1u);
+    {
+        T *po = O + i * o.si;
+        auto put = [&](auto &rec) {
+            if (mine) {
+#pragma unroll
+                for (int c = 0; c < ROUT; ++c) po[c * o.sc] = rec[c];
+            }
+        };
+        if constexpr (OP == SP_SOLVE) {
+            T x[N];
+            ldl_solve<T, N>(m, v, x);
+            put(x);
+        } else if constexpr (OP == SP_DET) {
+            if (mine) po[0] = det;
+        } else if constexpr (OP == SP_INV) {
+            ldl_inverse<T, N>(m);
+            put(m);
+        } else {
+            T dg[N];
+            ldl_inverse_diag<T, N>(m, dg);
+            put(dg);
+        }
+    }
+    if (__builtin_expect(bad == 0, 1)) return;
+    const roww::RowStrides st{a.si, a.sc, b.si, b.sc, o.si, o.sc};
+#pragma unroll 1
+    for (int pass = 0; pass < NG; ++pass) {
+        const int64_t m0 = tile0 + FM * pass;
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid)); // (see spd_kernel)
+        if (((bad >> pass) & 1u) && m0 < n)
+            roww::roww_tile<T, N, roww_op(OP), FR, false, FM, true>(A, B, O, n, m0, p, smem, tid, st);
+        __syncthreads();
+    }
+}
+
+template <typename T, int N, int OP>
+static int launch_strided(const SOp &a, const SOp &b, const SOp &o, int64_t no, int64_t n, const RowParams<T> &p, void *stream)
+{
+    constexpr size_t lds = roww::tile_lds_bytes<T, N, roww_op(OP), false, (sizeof(T) == 8 ? 4 : 16)>();
+    static_assert(lds <= 64 * 1024, "the fallback's tile must fit the default dynamic LDS limit");
+    if (n == 0 || no == 0) return NFM_OK;
+    const int64_t nblk = (n + 63) / 64;
+    if (nblk > 0x7fffffffLL || no > 65535) return NFM_EFALLBACK_RW;
+    hipLaunchKernelGGL((spd_strided_kernel<T, N, OP>), dim3((unsigned)nblk, (unsigned)no), dim3(64), lds,
+                       static_cast<hipStream_t>(stream), a, b, o, n, p);
+    return launch_status();
+}
+
+template <typename T, int N>
+static int call_strided(int op, const SOp &a, const SOp &b, const SOp &o, int64_t no, int64_t n, const RowParams<T> &p,
+                        void *stream)
+{
+    switch (op) {
+    case SP_SOLVE: return launch_strided<T, N, SP_SOLVE>(a, b, o, no, n, p, stream);
+    case SP_INV:
+        if constexpr (sizeof(T) == 8 && N >= 14) return NFM_EFALLBACK_RW; // (see call)
+        else return launch_strided<T, N, SP_INV>(a, b, o, no, n, p, stream);
+    case SP_INVDIAG: return launch_strided<T, N, SP_INVDIAG>(a, b, o, no, n, p, stream);
+    case SP_DET: return launch_strided<T, N, SP_DET>(a, b, o, no, n, p, stream);
+    default: return NFM_EINVAL;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // batchinv / batchdet of GENERAL matrices at orders 9..16: DIAGONAL PIVOTS FIRST (nfm_smallmat.hpp:
 // gj_inverse_nopivot / lu_det_nopivot).  Same frame as above: one matrix per lane on N^2 registers, the elimination
 // without row exchanges accepts the diagonal while it is within a factor 8 of the column maximum, the wavefront votes,
@@ -538,6 +658,27 @@ int NFM_SPD_NAME1(NFM_SPD_Q)(int op, int M, int64_t n, const void *a, const void
     return NFM_EFALLBACK_RW;
 }
 
+#if NFM_SPD_F64
+#define NFM_SPD_SNAME2(q) spd_call_strided_f64_q##q
+#else
+#define NFM_SPD_SNAME2(q) spd_call_strided_f32_q##q
+#endif
+#define NFM_SPD_SNAME1(q) NFM_SPD_SNAME2(q)
+int NFM_SPD_SNAME1(NFM_SPD_Q)(int op, int M, int64_t no, int64_t n, const nfm_operand *a, const nfm_operand *b,
+                              const nfm_operand *o, const double *eps, void *stream)
+{
+    spd::RowParams<TS> p;
+    p.has_eps = eps != nullptr;
+    for (int i = 0; i < NFM_MAX_DIM; ++i) p.eps[i] = (eps && i < M) ? (TS)eps[i] : TS(0);
+    auto sop = [](const nfm_operand *x) {
+        return x ? spd::SOp{x->ptr, x->stride_outer, x->stride_inner, x->stride_col} : spd::SOp{nullptr, 0, 0, 0};
+    };
+    const spd::SOp sa = sop(a), sb = sop(b), so = sop(o);
+    if (M == 9 + 2 * NFM_SPD_Q) return spd::call_strided<TS, 9 + 2 * NFM_SPD_Q>(op, sa, sb, so, no, n, p, stream);
+    if (M == 10 + 2 * NFM_SPD_Q) return spd::call_strided<TS, 10 + 2 * NFM_SPD_Q>(op, sa, sb, so, no, n, p, stream);
+    return NFM_EFALLBACK_RW;
+}
+
 #if NFM_SPD_Q == 0
 // the front end lives in the q0 object of each dtype
 static bool spd_contig(const nfm_operand *o, int64_t rec, size_t elem)
@@ -587,6 +728,47 @@ int Spd<TS>::sym_invert(int M, int diag_only, int64_t ni, const nfm_operand *mat
     if (M < 9 || M > 16 || !spd_contig(mat, K, sizeof(TS)) || !spd_contig(out, diag_only ? M : K, sizeof(TS)))
         return NFM_EFALLBACK_RW;
     return spd_dispatch(diag_only ? SP_INVDIAG : SP_INV, M, ni, mat->ptr, nullptr, out->ptr, nullptr, stream);
+}
+
+#if NFM_SPD_F64
+#define NFM_SPD_SCALL(q) spd_call_strided_f64_q##q
+#else
+#define NFM_SPD_SCALL(q) spd_call_strided_f32_q##q
+#endif
+static int spd_dispatch_strided(int op, int M, int64_t no, int64_t n, const nfm_operand *a, const nfm_operand *b,
+                                const nfm_operand *o, const double *eps, void *stream)
+{
+    static const int off = [] { const char *e = roww::dbg_env("NFM_SPD_OFF"); return e ? atoi(e) : 0; }();
+    if (off == 1 || off == 3) return NFM_EFALLBACK_RW; // (3: only the strided kernels off)
+    if (M < 9 || M > 16 || a == nullptr || a->ptr == nullptr || o == nullptr || o->ptr == nullptr) return NFM_EFALLBACK_RW;
+    switch ((M - 9) >> 1) {
+    case 0: return NFM_SPD_SCALL(0)(op, M, no, n, a, b, o, eps, stream);
+    case 1: return NFM_SPD_SCALL(1)(op, M, no, n, a, b, o, eps, stream);
+    case 2: return NFM_SPD_SCALL(2)(op, M, no, n, a, b, o, eps, stream);
+    case 3: return NFM_SPD_SCALL(3)(op, M, no, n, a, b, o, eps, stream);
+    default: return NFM_EFALLBACK_RW;
+    }
+}
+
+template <>
+int Spd<TS>::sym_solve_strided(int M, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
+                               const nfm_operand *out, const double *eps, void *stream)
+{
+    if (vec == nullptr || vec->ptr == nullptr) return NFM_EFALLBACK_RW;
+    return spd_dispatch_strided(SP_SOLVE, M, no, ni, mat, vec, out, eps, stream);
+}
+
+template <>
+int Spd<TS>::sym_invert_strided(int M, int diag_only, int64_t no, int64_t ni, const nfm_operand *mat,
+                                const nfm_operand *out, void *stream)
+{
+    return spd_dispatch_strided(diag_only ? SP_INVDIAG : SP_INV, M, no, ni, mat, nullptr, out, nullptr, stream);
+}
+
+template <>
+int Spd<TS>::sym_det_strided(int M, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream)
+{
+    return spd_dispatch_strided(SP_DET, M, no, ni, mat, nullptr, out, nullptr, stream);
 }
 
 template <>

@@ -10,8 +10,10 @@ namespace nfm {
 enum { SP_SOLVE = 0, SP_INV, SP_INVDIAG, SP_DET, SP_GINV, SP_GDET }; // G*: general (full, row-major) matrices
 
 // one object per (dtype, pair of orders): part = dtype * 4 + q holds orders 9 + 2 q and 10 + 2 q
-#define NFM_SPD_DECL(S, Q) \
-    int spd_call_##S##_q##Q(int op, int M, int64_t n, const void *a, const void *b, void *o, const double *eps, void *stream);
+#define NFM_SPD_DECL(S, Q)                                                                                                      \
+    int spd_call_##S##_q##Q(int op, int M, int64_t n, const void *a, const void *b, void *o, const double *eps, void *stream); \
+    int spd_call_strided_##S##_q##Q(int op, int M, int64_t no, int64_t n, const nfm_operand *a, const nfm_operand *b,          \
+                                    const nfm_operand *o, const double *eps, void *stream);
 NFM_SPD_DECL(f32, 0) NFM_SPD_DECL(f32, 1) NFM_SPD_DECL(f32, 2) NFM_SPD_DECL(f32, 3)
 NFM_SPD_DECL(f64, 0) NFM_SPD_DECL(f64, 1) NFM_SPD_DECL(f64, 2) NFM_SPD_DECL(f64, 3)
 #undef NFM_SPD_DECL
@@ -22,6 +24,13 @@ struct Spd {
                          const double *eps, void *stream);
     static int sym_invert(int M, int diag_only, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream);
     static int sym_det(int M, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream);
+    // the same for ANY strides of the compact operands (channel-first fields, padded / interleaved records, one vector
+    // for every matrix) and a second batch level: every lane addresses its own record, element by element
+    static int sym_solve_strided(int M, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
+                                 const nfm_operand *out, const double *eps, void *stream);
+    static int sym_invert_strided(int M, int diag_only, int64_t no, int64_t ni, const nfm_operand *mat,
+                                  const nfm_operand *out, void *stream);
+    static int sym_det_strided(int M, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *out, void *stream);
     static int batch_inv(int N, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream);
     static int batch_det(int N, int64_t ni, const nfm_operand *a, const nfm_operand *out, void *stream);
 };

@@ -397,6 +397,10 @@ static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operan
             const int rc = Large<T>::sym_solve(M, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
+        if (kind == NFM_MAT_SYM) { // any strides, two batch levels: every lane addresses its own record (nfm_spd.hip)
+            const int rc = Spd<T>::sym_solve_strided(M, no, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         return big_sym_solve<T>(M, kind, no, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
     }
     switch (kind) {
@@ -470,6 +474,10 @@ static int sym_invert_t(int M, int diag_only, int64_t no, int64_t ni, const nfm_
             const int rc = Large<T>::sym_invert(M, ni, mat, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
+        { // any strides, two batch levels (nfm_spd.hip)
+            const int rc = Spd<T>::sym_invert_strided(M, diag_only, no, ni, mat, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         return big_sym_invert<T>(M, diag_only, no, ni, mat, out, stream);
     }
     NoParams p{0};
@@ -495,6 +503,10 @@ static int sym_det_t(int M, int64_t no, int64_t ni, const nfm_operand *mat, cons
         }
         if (no == 1) {
             const int rc = Large<T>::sym_det(M, ni, mat, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
+        { // any strides, two batch levels (nfm_spd.hip)
+            const int rc = Spd<T>::sym_det_strided(M, no, ni, mat, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
         return big_sym_det<T>(M, no, ni, mat, out, stream);

@@ -113,7 +113,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
         ncs.append(1)
     ops.append(out)
     ncs.append(1)
-    b = Batch(batch, ops, ncs, pack=N > 8 and kind == _lib.MAT_SYM)
+    b = Batch(batch, ops, ncs, pack='all' if (N > 8 and kind == _lib.MAT_SYM) else False)
     o = b.operands
     o_inp = ctypes.byref(o[2]) if inp is not None else None
     with on_device(dev):
@@ -234,7 +234,9 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
         return _bigorder.sym_solve(mat, vec, eps, out, mat.shape[-1])
     matv, mat_nc = _full_view(mat, N, kind)
     batch = broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
-    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if N <= 8 else None)
+    # (orders 9..16 of compact matrices take component-major fields as they are since round 3 -- `spd_strided_kernel`
+    # -- so channel-first input gets channel-first output at every order; Batch packs what is strided along the batch)
+    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if (N <= 8 or kind == _lib.MAT_SYM) else None)
     b = Batch(batch, [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1), out], [mat_nc, 1, 1],
               pack=N > 8 and kind == _lib.MAT_SYM)
     o = b.operands
@@ -286,8 +288,10 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
         from . import _bigorder
         return _bigorder.sym_invert(mat, M, bool(diag), out)
     batch = mat.shape[:-1]
-    out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=mat if M <= 8 else None)
-    b = Batch(batch, [mat, out], [1, 1], pack=M > 8 and not diag)
+    # float64 inverses at 14..16 are the one case the strided kernels of orders 9..16 do not cover: contiguous output
+    uncovered = M >= 14 and not diag and dtype == torch.float64
+    out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=None if uncovered else mat)
+    b = Batch(batch, [mat, out], [1, 1], pack=('all' if uncovered else True) if (M > 8 and not diag) else False)
     o = b.operands
     with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_invert(

@@ -329,3 +329,64 @@ def test_general_large_orders_diagonal_pivots_first(dev, oracle, dn, n):
     keep[[17, 99]] = False
     assert relerr(got[keep], ref[keep]) <= TOL[dn] and not np.isfinite(got[17]).all() and np.isnan(got[99]).any()
     assert B.batchdet(t(a, dev)).cpu().numpy()[17] == 0
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [9, 12, 13, 16])
+def test_sym_large_orders_any_strides(dev, oracle, dn, M):
+    """orders 9..16 with channel-first fields, two batch levels, padded / interleaved records and a broadcast
+    vector: the strided positive-definite-first kernel (`spd_strided_kernel`, nfm_spd.hip) -- every lane addresses
+    its own record element by element, the fallback gathers / scatters its group -- on batches with indefinite
+    matrices mixed in, all four ops, out= buffers of every layout, in place."""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    K = M * (M + 1) // 2
+    S = N().sym
+    B, X, Y = 2, 19, 11
+    n = B * X * Y
+    tol = 4 * TOL[dn]
+    for every in (0, 29):
+        if every:
+            mat, vec, _ = sym_indefinite_np(n, M, dtype, 300 + M, every)
+        else:
+            mat, vec = spd_np(n, M, dtype, 300 + M)
+        ref, refi = oracle.sym_solve(mat, vec), oracle.sym_invert(mat)
+        refd, refdet = oracle.sym_invert(mat, diag=True), oracle.sym_det(mat).astype(np.float64)
+        mat4, vec4 = t(mat, dev).reshape(B, X, Y, K), t(vec, dev).reshape(B, X, Y, M)
+        # (B, C, X, Y) channel-first storage viewed channel-last: no copy, two batch levels
+        mat_cf = mat4.movedim(-1, 1).contiguous().movedim(1, -1)
+        vec_cf = vec4.movedim(-1, 1).contiguous().movedim(1, -1)
+        assert not mat_cf.is_contiguous()
+        assert relerr(S.sym_solve(mat_cf, vec_cf).cpu().numpy().reshape(n, M), ref) <= tol
+        assert relerr(S.sym_solve(mat_cf, vec4).cpu().numpy().reshape(n, M), ref) <= tol          # mixed layouts
+        assert relerr(S.sym_invert(mat_cf).cpu().numpy().reshape(n, K), refi) <= tol
+        assert relerr(S.sym_invert(mat_cf, diag=True).cpu().numpy().reshape(n, M), refd) <= tol
+        d = S.sym_det(mat_cf).cpu().numpy().astype(np.float64).reshape(n)
+        assert np.abs(d / refdet - 1).max() <= 16 * TOL[dn]
+        # channel-first output buffers through out=
+        out_cf = torch.empty(B, M, X, Y, dtype=vec4.dtype, device=dev).movedim(1, -1)
+        r = S.sym_solve(mat_cf, vec_cf, out=out_cf)
+        assert r.data_ptr() == out_cf.data_ptr() and relerr(out_cf.cpu().numpy().reshape(n, M), ref) <= tol
+        inv_cf = torch.empty(B, K, X, Y, dtype=vec4.dtype, device=dev).movedim(1, -1)
+        S.sym_invert(mat_cf, out=inv_cf)
+        assert relerr(inv_cf.cpu().numpy().reshape(n, K), refi) <= tol
+        # pure SoA: (K, n).T; in place on channel-first storage
+        mat_soa, vec_soa = t(mat, dev).t().contiguous().t(), t(vec, dev).t().contiguous().t()
+        assert relerr(S.sym_solve(mat_soa, vec_soa).cpu().numpy(), ref) <= tol
+        v2 = vec_soa.clone(memory_format=torch.preserve_format)
+        S.sym_solve_(mat_soa, v2)
+        assert relerr(v2.cpu().numpy(), ref) <= tol
+        m2 = mat_soa.clone(memory_format=torch.preserve_format)
+        S.sym_invert_(m2)
+        assert relerr(m2.cpu().numpy(), refi) <= tol
+        # every other record, padded records, one vector for every matrix
+        assert relerr(S.sym_solve(t(mat, dev)[::2], t(vec, dev)[::2]).cpu().numpy(), ref[::2]) <= tol
+        pad = torch.zeros(n, K + 3, dtype=mat4.dtype, device=dev)
+        pad[:, :K] = t(mat, dev)
+        assert relerr(S.sym_solve(pad[:, :K], t(vec, dev)).cpu().numpy(), ref) <= tol
+        assert relerr(S.sym_invert(pad[:, :K]).cpu().numpy(), refi) <= tol
+        ref_b = oracle.sym_solve(mat, np.broadcast_to(vec[:1], (n, M)))
+        assert relerr(S.sym_solve(t(mat, dev), t(vec[0], dev)).cpu().numpy(), ref_b) <= tol
+        # eps through the strided kernel
+        e = 0.25
+        assert relerr(S.sym_solve(mat_cf, vec_cf, eps=e).cpu().numpy().reshape(n, M),
+                      oracle.sym_solve(mat + np.r_[np.full(M, e), np.zeros(K - M)].astype(dtype), vec)) <= 4 * tol
