@@ -61,7 +61,16 @@ def test_batch_pack_leaves_broadcasts_alone():
     mat = torch.zeros(78, 50).t()                        # channel-first 12x12 compact field
     one = torch.zeros(1, 12)                             # one vector for every matrix
     out = torch.zeros(50, 12)
+    # pack=True (round 3): component-major fields stay as they are (the strided kernels of orders 9..16 read them
+    # with consecutive lanes on consecutive addresses), records strided along the batch are packed
     b = Batch((50,), [mat, expand_batch((50,), one, 1), out], [1, 1, 1], pack=True)
+    assert b.tensors[0] is mat and b.operands[0].stride_inner == 1 and b.operands[0].stride_col == 50
+    assert b.tensors[1].stride(0) == 0 and b.operands[1].stride_inner == 0  # broadcast kept
+    every_other = torch.zeros(100, 78)[::2]
+    b = Batch((50,), [every_other, expand_batch((50,), one, 1), out], [1, 1, 1], pack=True)
+    assert b.tensors[0].is_contiguous() and b.tensors[0] is not every_other and b.operands[0].stride_inner == 78
+    # pack='all' (ops without a strided kernel): component-major fields are packed too
+    b = Batch((50,), [mat, expand_batch((50,), one, 1), out], [1, 1, 1], pack='all')
     assert b.tensors[0].is_contiguous() and b.tensors[0] is not mat         # packed
     assert b.tensors[1].stride(0) == 0                                       # broadcast kept
     assert b.operands[1].stride_inner == 0 and b.operands[0].stride_inner == 78
