@@ -328,7 +328,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
         for (int k = 0; k < NG; ++k) bad |= ((badl >> (k * FM)) & ((1ull << FM) - 1ull)) ? (1u << k) : 0u;
     }
     const bool mine = live && !((bad >> (threadIdx.x / FM)) & 1u); // this lane's result is stored by this path
-    {
+    if (bad != (1u << NG) - 1u) { // (every group bad: nothing to finish or store here)
         // the result record of the lane: through the LDS image again (whole-line stores), or straight from the lane
         auto put = [&](auto &rec) {
             if constexpr (TILED) {
@@ -425,7 +425,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
         for (int k = 0; k < NG; ++k) bad |= ((badl >> (k * FM)) & ((1ull << FM) - 1ull)) ? (1u << k) : 0u;
     }
     const bool mine = live && !((bad >> (threadIdx.x / FM)) & 1u);
-    {
+    if (bad != (1u << NG) - 1u) { // (every group bad: nothing to finish or store here)
         T *po = O + i * o.si;
         auto put = [&](auto &rec) {
             if (mine) {
