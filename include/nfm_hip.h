@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NFM_VERSION 4 /* 2: nfm_qr_eig_sym takes flags (NFM_EIG_*); nfm_reduce_median added; 3: nfm_reduce_median_mid;
+#define NFM_VERSION 5 /* 5: NFM_MAT_PIVOTED / NFM_INVERT_PIVOTED; 2: nfm_qr_eig_sym takes flags (NFM_EIG_*); nfm_reduce_median added; 3: nfm_reduce_median_mid;
                          4: nfm_qr_eig_sym flags: bit 2 is NFM_EIG_FAST (flags == with_u is the reference order again) */
 #define NFM_MAX_DIM 16 /* largest matrix order handled (3x3 .. 16x16 and below) */
 
@@ -59,6 +59,12 @@ extern "C" {
 #define NFM_MAT_DIAG 1 /* NN = M       diagonal           */
 #define NFM_MAT_SCAL 2 /* NN = 1       scaled identity    */
 #define NFM_MAT_FULL 3 /* NN = M*M     full, row-major via stride_row/stride_col */
+/* flag, OR-ed into `mat_kind` of nfm_sym_solve (and bit 1 = value 2 of `diag_only` of nfm_sym_invert): orders 9..16 go
+ * straight to the pivoted elimination, without the attempt that serves positive definite matrices -- for callers who
+ * know their matrices are indefinite (a batch of those pays the attempt for nothing) */
+#define NFM_MAT_PIVOTED 16
+#define NFM_INVERT_DIAG 1
+#define NFM_INVERT_PIVOTED 2
 
 typedef struct nfm_operand {
     void *ptr;            /* device pointer */
@@ -92,10 +98,11 @@ int nfm_sym_matvec(int dtype, int M, int mat_kind, int mode, int64_t n_outer, in
                    const nfm_operand *mat, const nfm_operand *vec, const nfm_operand *inp,
                    const nfm_operand *out, void *stream);
 
-/* out = compact inverse of a compact symmetric matrix (diag_only: its M diagonal
- * entries).  Replaces `sym_invert` / `sym_invert_` (`sym.py:34`, `_impl/sym.py:455-493`).
- * One factorisation per matrix (the reference runs M full solves).  `out` may alias `mat`
- * when diag_only == 0. */
+/* out = compact inverse of a compact symmetric matrix (diag_only & NFM_INVERT_DIAG: its M
+ * diagonal entries; diag_only & NFM_INVERT_PIVOTED: see NFM_MAT_PIVOTED).  Replaces
+ * `sym_invert` / `sym_invert_` (`sym.py:34`, `_impl/sym.py:455-493`).  One factorisation per
+ * matrix (the reference runs M full solves).  `out` may alias `mat` when the diagonal flag
+ * is not set. */
 int nfm_sym_invert(int dtype, int M, int diag_only, int64_t n_outer, int64_t n_inner,
                    const nfm_operand *mat, const nfm_operand *out, void *stream);
 

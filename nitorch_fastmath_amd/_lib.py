@@ -15,6 +15,7 @@ F32, F64 = 0, 1
 MAT_SYM, MAT_DIAG, MAT_SCAL, MAT_FULL = 0, 1, 2, 3
 FLAG_TS_PERTURB = 1
 EIG_VECTORS, EIG_FAST = 1, 2                 # flags of nfm_qr_eig_sym
+MAT_PIVOTED, INVERT_PIVOTED = 16, 2          # include/nfm_hip.h: NFM_MAT_PIVOTED, NFM_INVERT_PIVOTED
 RED_NANSUM, RED_NANMAX, RED_NANMIN, RED_SUM, RED_MAX, RED_MIN, RED_NANCOUNT, RED_NANSUMSQ = range(8)
 MAX_DIM = 16
 SIDE = {'left': 0, 'right': 1, 'both': 2}

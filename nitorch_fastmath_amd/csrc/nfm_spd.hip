@@ -38,6 +38,18 @@ namespace spd {
 
 using roww::RowParams;
 
+// rows per lane of the fallback (FR; 16 / FR lanes per matrix, 4 FR matrices per pass).  4 in both dtypes: with one
+// row per lane (16 passes of 4 matrices) a float64 batch in which every matrix is indefinite ran 5x behind the
+// pivoted kernels alone
+#ifndef NFM_SPD_FR64
+#define NFM_SPD_FR64 4
+#endif
+template <typename T>
+constexpr int fallback_rows()
+{
+    return sizeof(T) == 8 ? NFM_SPD_FR64 : 4;
+}
+
 constexpr int roww_op(int op)
 {
     return op == SP_SOLVE ? roww::RW_SOLVE_SYM : op == SP_INV ? roww::RW_INV_SYM
@@ -259,7 +271,7 @@ template <typename T, int N, int OP>
 constexpr size_t spd_lds_bytes()
 {
     constexpr int ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? sym_k(N) : OP == SP_INVDIAG ? N : 1;
-    size_t b = roww::tile_lds_bytes<T, N, roww_op(OP), false, (sizeof(T) == 8 ? 4 : 16)>();
+    size_t b = roww::tile_lds_bytes<T, N, roww_op(OP), false, 4 * fallback_rows<T>()>();
     if (spd_tiled<T, N>()) {
         const size_t tm = TileIO<T, sym_k(N), 64>::kLdsBytes, tr = TileIO<T, ROUT, 64>::kLdsBytes;
         const size_t tv = TileIO<T, N, 64>::kLdsBytes;
@@ -320,7 +332,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
     // the vote.  Matrices go to the fallback in groups of FM = what one of its passes works on; every other lane of
     // the wavefront finishes and stores as if nothing had happened (the groups of the bad matrices store nothing: an
     // in-place call must leave their input for the fallback)
-    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR, NG = 64 / FM;
+    constexpr int FR = fallback_rows<T>(), FM = 4 * FR, NG = 64 / FM;
     const unsigned long long badl = __ballot(!ok);
     unsigned bad = 0;
     if (__builtin_expect(badl != 0, 0)) {
@@ -417,7 +429,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
     }
     T det;
     const bool ok = ldl_factor<T, N>(m, det);
-    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR, NG = 64 / FM;
+    constexpr int FR = fallback_rows<T>(), FM = 4 * FR, NG = 64 / FM;
     const unsigned long long badl = __ballot(!ok);
     unsigned bad = 0;
     if (__builtin_expect(badl != 0, 0)) {
@@ -464,7 +476,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
 template <typename T, int N, int OP>
 static int launch_strided(const SOp &a, const SOp &b, const SOp &o, int64_t no, int64_t n, const RowParams<T> &p, void *stream)
 {
-    constexpr size_t lds = roww::tile_lds_bytes<T, N, roww_op(OP), false, (sizeof(T) == 8 ? 4 : 16)>();
+    constexpr size_t lds = roww::tile_lds_bytes<T, N, roww_op(OP), false, 4 * fallback_rows<T>()>();
     static_assert(lds <= 64 * 1024, "the fallback's tile must fit the default dynamic LDS limit");
     if (n == 0 || no == 0) return NFM_OK;
     const int64_t nblk = (n + 63) / 64;
@@ -512,7 +524,7 @@ constexpr int gen_max_waves()
 template <typename T, int N, int OP>
 constexpr size_t gen_lds_bytes()
 {
-    size_t b = roww::tile_lds_bytes<T, N, roww_op(OP), false, (sizeof(T) == 8 ? 4 : 16)>();
+    size_t b = roww::tile_lds_bytes<T, N, roww_op(OP), false, 4 * fallback_rows<T>()>();
     const size_t t = SubOut<T, N * N, gen_out_subs<T, N>()>::kLdsBytes; // (the way in uses the same geometry)
     b = b > t ? b : t;
     return b;
@@ -537,7 +549,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, gen_max_waves<T, N>()))) __laun
     for (int r = 0; r < N; ++r)
 #pragma unroll
         for (int c = 0; c < N; ++c) a[r][c] = f[r * N + c];
-    constexpr int FR = sizeof(T) == 8 ? 1 : 4, FM = 4 * FR, NG = 64 / FM;
+    constexpr int FR = fallback_rows<T>(), FM = 4 * FR, NG = 64 / FM;
     bool ok;
     T det = T(0);
     if constexpr (OP == SP_GDET) det = lu_det_nopivot<T, N>(a, ok);

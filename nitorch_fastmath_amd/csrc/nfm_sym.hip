@@ -368,7 +368,7 @@ static int sym_bcast_big(int M, int kind, int mode, int64_t no, int64_t ni, cons
 
 template <typename T>
 static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
-                       const nfm_operand *out, const SolveParams &p, void *stream)
+                       const nfm_operand *out, const SolveParams &p, void *stream, bool pivoted = false)
 {
     // a matrix that is the same along the inner batch level (stride 0: one Hessian, many gradients)
     if (kind == NFM_MAT_SYM && M >= 2 && M <= 8 && mat->stride_inner == 0 && ni >= 1024) {
@@ -386,7 +386,7 @@ static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operan
         return sym_bcast_big<T, BB_SOLVE>(M, kind, 0, no, ni, mat, vec, nullptr, out, p, stream);
     if (M > 8) {
         if (kind == NFM_MAT_SYM && no == 1) { // contiguous operands: registers; else LDS-resident
-            { // positive definite first, pivoted elimination for the wavefronts that need it (nfm_spd.hip)
+            if (!pivoted) { // positive definite first, pivoted elimination for the groups that need it (nfm_spd.hip)
                 const int rc = Spd<T>::sym_solve(M, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
                 if (rc != NFM_EFALLBACK) return rc;
             }
@@ -397,7 +397,7 @@ static int sym_solve_t(int M, int kind, int64_t no, int64_t ni, const nfm_operan
             const int rc = Large<T>::sym_solve(M, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
-        if (kind == NFM_MAT_SYM) { // any strides, two batch levels: every lane addresses its own record (nfm_spd.hip)
+        if (kind == NFM_MAT_SYM && !pivoted) { // any strides, two batch levels: every lane addresses its own record (nfm_spd.hip)
             const int rc = Spd<T>::sym_solve_strided(M, no, ni, mat, vec, out, p.has_eps ? p.eps : nullptr, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
@@ -458,11 +458,13 @@ static int sym_matvec_t(int M, int kind, int mode, int64_t no, int64_t ni, const
 }
 
 template <typename T>
-static int sym_invert_t(int M, int diag_only, int64_t no, int64_t ni, const nfm_operand *mat,
+static int sym_invert_t(int M, int flags, int64_t no, int64_t ni, const nfm_operand *mat,
                         const nfm_operand *out, void *stream)
 {
+    const int diag_only = flags & NFM_INVERT_DIAG;
+    const bool pivoted = (flags & NFM_INVERT_PIVOTED) != 0;
     if (M > 8) {
-        if (no == 1) { // positive definite first (nfm_spd.hip)
+        if (no == 1 && !pivoted) { // positive definite first (nfm_spd.hip)
             const int rc = Spd<T>::sym_invert(M, diag_only, ni, mat, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
@@ -474,7 +476,7 @@ static int sym_invert_t(int M, int diag_only, int64_t no, int64_t ni, const nfm_
             const int rc = Large<T>::sym_invert(M, ni, mat, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
-        { // any strides, two batch levels (nfm_spd.hip)
+        if (!pivoted) { // any strides, two batch levels (nfm_spd.hip)
             const int rc = Spd<T>::sym_invert_strided(M, diag_only, no, ni, mat, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
@@ -573,6 +575,8 @@ int nfm_sym_solve(int dtype, int M, int mat_kind, int64_t n_outer, int64_t n_inn
     int rc = check_common(dtype, n_outer, n_inner);
     if (rc) return rc;
     if (M < 1 || M > NFM_MAX_DIM) return NFM_ESIZE;
+    const bool pivoted = (mat_kind & NFM_MAT_PIVOTED) != 0;
+    mat_kind &= ~NFM_MAT_PIVOTED;
     if (mat_kind < 0 || mat_kind > 3) return NFM_EINVAL;
     const bool nonempty = n_outer > 0 && n_inner > 0;
     if ((rc = check_operand(mat, dtype, nonempty))) return rc;
@@ -581,8 +585,8 @@ int nfm_sym_solve(int dtype, int M, int mat_kind, int64_t n_outer, int64_t n_inn
     SolveParams p;
     p.has_eps = eps != nullptr;
     for (int i = 0; i < NFM_MAX_DIM; ++i) p.eps[i] = (eps && i < M) ? eps[i] : 0.0;
-    return dtype == NFM_F32 ? sym_solve_t<float>(M, mat_kind, n_outer, n_inner, mat, vec, out, p, stream)
-                            : sym_solve_t<double>(M, mat_kind, n_outer, n_inner, mat, vec, out, p, stream);
+    return dtype == NFM_F32 ? sym_solve_t<float>(M, mat_kind, n_outer, n_inner, mat, vec, out, p, stream, pivoted)
+                            : sym_solve_t<double>(M, mat_kind, n_outer, n_inner, mat, vec, out, p, stream, pivoted);
 }
 
 int nfm_sym_matvec(int dtype, int M, int mat_kind, int mode, int64_t n_outer, int64_t n_inner,

@@ -59,6 +59,17 @@ def _mat_kind(NN, N):
                      f'expected 1, {N}, {N * (N + 1) // 2} or {N * N}')
 
 
+# orders 9..16 of sym_solve / sym_invert: 'auto' = positive definite first, 'always' = pivoted at once
+PIVOTING = 'auto'
+
+
+def _pivoting(pivoting):
+    mode = PIVOTING if pivoting is None else pivoting
+    if mode not in ('auto', 'always'):
+        raise ValueError(f"pivoting must be 'auto' or 'always', got {mode!r}")
+    return mode == 'always'
+
+
 def _prep(dtype, *tensors):
     tensors = [None if t is None else torch.as_tensor(t) for t in tensors]
     dev = require_gpu(*tensors)
@@ -197,7 +208,7 @@ def _require_inplace_ok(t, shape):
                          f'{tuple(shape)} (it cannot be broadcast)')
 
 
-def sym_solve(mat, vec, eps=None, dtype=None, out=None):
+def sym_solve(mat, vec, eps=None, dtype=None, out=None, *, pivoting=None):
     r"""Left matrix division for compact symmetric matrices: `mat \ vec`.
 
     Replaces `nitorch_fastmath.sym.sym_solve` (in-repo: `_impl/sym.py:327-398`).
@@ -212,6 +223,10 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     eps : `float or (M,) sequence[float]`, optional
         Smoothing term added to the diagonal of `mat` (last value repeated).
     dtype, out : optional
+    pivoting : {'auto', 'always'}, keyword-only, default `sym.PIVOTING` = 'auto'
+        Orders 9..16.  'auto': the unpivoted LDL^T first -- positive definite matrices, what Hessians are -- and the
+        pivoted elimination for the groups of matrices that are not; 'always': the pivoted elimination at once (a
+        batch of INDEFINITE matrices pays the attempt for nothing: up to 2x).  Same answers within rounding.
 
     Returns
     -------
@@ -236,9 +251,11 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
     batch = broadcast_shapes(mat.shape[:-1], vec.shape[:-1])
     # (orders 9..16 of compact matrices take component-major fields as they are since round 3 -- `spd_strided_kernel`
     # -- so channel-first input gets channel-first output at every order; Batch packs what is strided along the batch)
-    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if (N <= 8 or kind == _lib.MAT_SYM) else None)
+    piv = _pivoting(pivoting)
+    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev,
+                        like=vec if (N <= 8 or (kind == _lib.MAT_SYM and not piv)) else None)
     b = Batch(batch, [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1), out], [mat_nc, 1, 1],
-              pack=N > 8 and kind == _lib.MAT_SYM)
+              pack=('all' if piv else True) if (N > 8 and kind == _lib.MAT_SYM) else False)
     o = b.operands
     eps_p = None
     if eps is not None:
@@ -249,8 +266,8 @@ def sym_solve(mat, vec, eps=None, dtype=None, out=None):
         eps_p = (ctypes.c_double * _lib.MAX_DIM)(*(e + [0.0] * (_lib.MAX_DIM - N)))
     with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_solve(
-            dtype_code(dtype), N, kind, b.n_outer, b.n_inner, ctypes.byref(o[0]), ctypes.byref(o[1]),
-            ctypes.byref(o[2]), eps_p, stream_ptr(dev)))
+            dtype_code(dtype), N, kind | (_lib.MAT_PIVOTED if piv else 0), b.n_outer, b.n_inner, ctypes.byref(o[0]),
+            ctypes.byref(o[1]), ctypes.byref(o[2]), eps_p, stream_ptr(dev)))
     b.finish()
     return out
 
@@ -261,7 +278,7 @@ def sym_solve_(mat, vec, eps=None):
     return sym_solve(mat, vec, eps=eps, dtype=vec.dtype, out=vec)
 
 
-def sym_invert(mat, diag=False, dtype=None, out=None):
+def sym_invert(mat, diag=False, dtype=None, out=None, *, pivoting=None):
     r"""Inverse of compact symmetric matrices, returned in compact storage.
 
     Replaces `nitorch_fastmath.sym.sym_invert` (in-repo: `_impl/sym.py:455-493`,
@@ -272,6 +289,7 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
     mat : `(..., M*(M+1)//2) tensor`
     diag : `bool`, default=False
         If True, only return the diagonal of the inverse, shape `(..., M)`.
+    pivoting : {'auto', 'always'}, keyword-only: see `sym_solve`.
     """
     from ._autograd import SymInvertFn, needs_grad
     if needs_grad(mat):
@@ -289,13 +307,14 @@ def sym_invert(mat, diag=False, dtype=None, out=None):
         return _bigorder.sym_invert(mat, M, bool(diag), out)
     batch = mat.shape[:-1]
     # float64 inverses at 14..16 are the one case the strided kernels of orders 9..16 do not cover: contiguous output
-    uncovered = M >= 14 and not diag and dtype == torch.float64
+    piv = _pivoting(pivoting)
+    uncovered = (M >= 14 and not diag and dtype == torch.float64) or piv
     out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=None if uncovered else mat)
     b = Batch(batch, [mat, out], [1, 1], pack=('all' if uncovered else True) if (M > 8 and not diag) else False)
     o = b.operands
     with on_device(dev):
         _lib.check(_lib.lib().nfm_sym_invert(
-            dtype_code(dtype), M, int(bool(diag)), b.n_outer, b.n_inner, ctypes.byref(o[0]),
+            dtype_code(dtype), M, int(bool(diag)) | (_lib.INVERT_PIVOTED if piv else 0), b.n_outer, b.n_inner, ctypes.byref(o[0]),
             ctypes.byref(o[1]), stream_ptr(dev)))
     b.finish()
     return out

@@ -40,7 +40,7 @@ def test_signature_table_matches_header():
 
 
 def test_version_and_strerror(L):
-    assert L.nfm_version() == 4
+    assert L.nfm_version() == 5
     assert b'dtype' in L.nfm_strerror(-2)
     assert L.nfm_reduce_workspace_bytes() >= 2048 * 8
 

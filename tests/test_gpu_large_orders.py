@@ -390,3 +390,28 @@ def test_sym_large_orders_any_strides(dev, oracle, dn, M):
         e = 0.25
         assert relerr(S.sym_solve(mat_cf, vec_cf, eps=e).cpu().numpy().reshape(n, M),
                       oracle.sym_solve(mat + np.r_[np.full(M, e), np.zeros(K - M)].astype(dtype), vec)) <= 4 * tol
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [9, 12, 16])
+def test_pivoting_always_skips_the_positive_definite_attempt(dev, oracle, dn, M):
+    """`pivoting='always'` (keyword-only extension, `sym.PIVOTING`; NFM_MAT_PIVOTED / NFM_INVERT_PIVOTED in the C ABI):
+    orders 9..16 go straight to the pivoted elimination -- for callers whose matrices are indefinite.  Same answers as
+    'auto' within the tolerance, on definite and indefinite batches, contiguous and channel-first operands."""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    S = N().sym
+    n = 700 + M
+    for every in (0, 1):
+        if every:
+            mat, vec, _ = sym_indefinite_np(n, M, dtype, 900 + M, 1)      # every matrix indefinite
+        else:
+            mat, vec = spd_np(n, M, dtype, 900 + M)
+        ref, refi = oracle.sym_solve(mat, vec), oracle.sym_invert(mat)
+        for m_, v_ in ((t(mat, dev), t(vec, dev)), (t(mat, dev).t().contiguous().t(), t(vec, dev).t().contiguous().t())):
+            for mode in ('auto', 'always'):
+                assert relerr(S.sym_solve(m_, v_, pivoting=mode).cpu().numpy(), ref) <= 4 * TOL[dn]
+                assert relerr(S.sym_invert(m_, pivoting=mode).cpu().numpy(), refi) <= 4 * TOL[dn]
+                assert relerr(S.sym_invert(m_, diag=True, pivoting=mode).cpu().numpy(),
+                              oracle.sym_invert(mat, diag=True)) <= 4 * TOL[dn]
+    with pytest.raises(ValueError):
+        S.sym_solve(t(mat, dev), t(vec, dev), pivoting='never')
