@@ -16,9 +16,12 @@
 //   * every pivot positive <=> the matrix is positive definite (Sylvester).  The wavefront votes: when every
 //     matrix passed, the lanes finish (solve: two triangular sweeps; inverse: W = U^-1, then W D^-1 W^T, in
 //     place; determinant: the product of the pivots) and store;
-//   * a wavefront with ONE matrix that did not pass drops its work and redoes its 64 matrices with the pivoted
-//     elimination of nfm_rowwave (4 lanes per matrix, 16 matrices per pass, straight from global memory): the
-//     answer for indefinite, singular and NaN input is what it was before this file existed.
+//   * the matrices that did not pass go to the pivoted elimination of nfm_rowwave in GROUPS of 16 (what one of its
+//     tiles works on); every other group finishes and stores as if nothing had happened.  When the output aliases no
+//     input, the bad groups are MARKED (a NaN in the first output element of the group's first matrix) and a second
+//     launch (`redo_kernel`) runs the elimination on the marked groups at the row-wave kernels' own occupancy; an
+//     in-place call has no place for a mark and its wavefronts redo their bad groups themselves.  The answer for
+//     indefinite, singular and NaN input is what it was before this file existed.
 //
 // Results differ from the LU's in rounding only (both are backward stable on these matrices); parity is asserted
 // through the tolerance of the tests, like every result beyond the closed forms.
@@ -284,7 +287,7 @@ constexpr size_t spd_lds_bytes()
 
 template <typename T, int N, int OP>
 __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __launch_bounds__(64) void spd_kernel(const T *__restrict__ A, const T *__restrict__ B, T *__restrict__ O,
-                                                 int64_t n, RowParams<T> p)
+                                                 int64_t n, RowParams<T> p, int mark)
 {
     constexpr int K = sym_k(N);
     constexpr int ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? K : OP == SP_INVDIAG ? N : 1;
@@ -365,6 +368,12 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
         }
     }
     if (__builtin_expect(bad == 0, 1)) return;
+    if (mark) { // uniform: the output does not alias an input -- the bad groups are left to `redo_kernel`, which runs
+                // right behind this one at the row-wave kernels' own occupancy; the MARK of a group is a NaN in the first
+                // output element of its first matrix (every good group has written that element by now)
+        if (threadIdx.x % FM == 0 && ((bad >> (threadIdx.x / FM)) & 1u) && live) O[i * ROUT] = (T)__builtin_nanf("");
+        return;
+    }
     // not positive definite somewhere in this wavefront: the pivoted elimination of nfm_rowwave on the groups that
     // hold such a matrix, FR rows per lane = FM matrices per pass (a pass reads its records before it writes: in-place
     // calls are safe).  float32: 4 rows per lane, up to 4 passes; float64: one row per lane, up to 16 passes -- 4 rows
@@ -532,7 +541,7 @@ constexpr size_t gen_lds_bytes()
 
 template <typename T, int N, int OP>
 __global__ __attribute__((amdgpu_waves_per_eu(1, gen_max_waves<T, N>()))) __launch_bounds__(64) void gen_kernel(
-    const T *__restrict__ A, T *__restrict__ O, int64_t n, RowParams<T> p)
+    const T *__restrict__ A, T *__restrict__ O, int64_t n, RowParams<T> p, int mark)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t tile0 = (int64_t)blockIdx.x * 64;
@@ -572,6 +581,11 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, gen_max_waves<T, N>()))) __laun
                                                                  (int)threadIdx.x, bad);
     }
     if (__builtin_expect(bad == 0, 1)) return;
+    if (mark) { // (see spd_kernel)
+        constexpr int ROUT = OP == SP_GDET ? 1 : N * N;
+        if (threadIdx.x % FM == 0 && ((bad >> (threadIdx.x / FM)) & 1u) && live) O[i * ROUT] = (T)__builtin_nanf("");
+        return;
+    }
     // a row exchange was needed somewhere in this wavefront: the pivoted elimination on the groups that hold such a matrix
 #pragma unroll 1
     for (int pass = 0; pass < NG; ++pass) {
@@ -583,6 +597,64 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, gen_max_waves<T, N>()))) __laun
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// the second launch: the groups the first one marked, at the row-wave kernels' own register count (4-8 wavefronts per
+// SIMD instead of the 1-2 of the kernels above, whose in-kernel fallback serves calls whose output aliases an input
+// -- there is no place for a mark then).  A workgroup of 128 lanes (2 rows per lane, 16 matrices per tile) reads the
+// marks of CH groups -- 16 scattered words; with nothing marked that is all the kernel does: n / 256 workgroups,
+// 64 bytes per group of 16 matrices, 5-10 us at 2e6 matrices -- and runs `roww_tile` on the marked ones.
+template <typename T, int N, int OP>
+__global__ __launch_bounds__(128) void redo_kernel(const T *__restrict__ A, const T *__restrict__ B, T *__restrict__ O,
+                                                   int64_t n, RowParams<T> p)
+{
+    constexpr int CH = 16; // groups per workgroup (64: a batch of indefinite matrices ran 64 tiles in a row per workgroup, too few in flight)
+    constexpr int ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? sym_k(N) : OP == SP_INVDIAG ? N
+                         : OP == SP_GINV ? N * N : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned long long marks;
+    const int64_t g0 = (int64_t)blockIdx.x * CH;
+    const int64_t ngroups = (n + 15) / 16;
+    if (threadIdx.x < 64) {
+        bool marked = false;
+        if (threadIdx.x < CH && g0 + threadIdx.x < ngroups) {
+            const T m = O[(g0 + threadIdx.x) * 16 * ROUT];
+            marked = m != m;
+        }
+        const unsigned long long b = __ballot(marked);
+        if (threadIdx.x == 0) marks = b;
+    }
+    __syncthreads();
+    const unsigned long long todo = marks;
+    if (todo == 0) return;
+#pragma unroll 1
+    for (int k = 0; k < CH; ++k) {
+        if (!((todo >> k) & 1ull)) continue; // uniform
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid)); // (see spd_kernel)
+        roww::roww_tile<T, N, roww_op(OP), 2, false, 16>(A, B, O, n, (g0 + k) * 16, p, smem, tid);
+        __syncthreads();
+    }
+}
+
+template <typename T, int N, int OP>
+static int launch_redo(const void *a, const void *b, void *o, int64_t n, const RowParams<T> &p, void *stream)
+{
+    constexpr size_t lds = roww::tile_lds_bytes<T, N, roww_op(OP), false, 16>();
+    static_assert(lds <= 64 * 1024, "the tile must fit the default dynamic LDS limit");
+    const int64_t nblk = ((n + 15) / 16 + 15) / 16;
+    hipLaunchKernelGGL((redo_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(128), lds, static_cast<hipStream_t>(stream),
+                       static_cast<const T *>(a), static_cast<const T *>(b), static_cast<T *>(o), n, p);
+    return launch_status();
+}
+
+// does the output overlap an input?  (byte ranges of contiguous operands)
+static bool ranges_overlap(const void *x, size_t xb, const void *y, size_t yb)
+{
+    if (x == nullptr || y == nullptr) return false;
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(x), b0 = reinterpret_cast<uintptr_t>(y);
+    return a0 < b0 + yb && b0 < a0 + xb;
+}
+
 template <typename T, int N, int OP>
 static int launch_gen(const void *a, void *o, int64_t n, void *stream)
 {
@@ -592,9 +664,13 @@ static int launch_gen(const void *a, void *o, int64_t n, void *stream)
     const int64_t nblk = (n + 63) / 64;
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
     RowParams<T> p{};
+    constexpr int64_t ROUT = OP == SP_GDET ? 1 : N * N;
+    const int mark = !ranges_overlap(o, (size_t)n * ROUT * sizeof(T), a, (size_t)n * N * N * sizeof(T));
     hipLaunchKernelGGL((gen_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(64), lds, static_cast<hipStream_t>(stream),
-                       static_cast<const T *>(a), static_cast<T *>(o), n, p);
-    return launch_status();
+                       static_cast<const T *>(a), static_cast<T *>(o), n, p, mark);
+    const int rc = launch_status();
+    if (rc != NFM_OK || !mark) return rc;
+    return launch_redo<T, N, OP>(a, nullptr, o, n, p, stream);
 }
 
 // the orders whose N^2 record (+ temporaries) the backend holds in a lane without scratch (scripts/survey_spd.sh)
@@ -612,9 +688,15 @@ static int launch(const void *a, const void *b, void *o, int64_t n, const RowPar
     if (n == 0) return NFM_OK;
     const int64_t nblk = (n + 63) / 64;
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    constexpr int64_t K = sym_k(N), ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? K : OP == SP_INVDIAG ? N : 1;
+    const size_t ob = (size_t)n * ROUT * sizeof(T);
+    const int mark = !ranges_overlap(o, ob, a, (size_t)n * K * sizeof(T)) &&
+                     !(OP == SP_SOLVE && ranges_overlap(o, ob, b, (size_t)n * N * sizeof(T)));
     hipLaunchKernelGGL((spd_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(64), lds, static_cast<hipStream_t>(stream),
-                       static_cast<const T *>(a), static_cast<const T *>(b), static_cast<T *>(o), n, p);
-    return launch_status();
+                       static_cast<const T *>(a), static_cast<const T *>(b), static_cast<T *>(o), n, p, mark);
+    const int rc = launch_status();
+    if (rc != NFM_OK || !mark) return rc;
+    return launch_redo<T, N, OP>(a, b, o, n, p, stream);
 }
 
 template <typename T, int N>
