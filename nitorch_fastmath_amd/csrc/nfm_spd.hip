@@ -26,6 +26,7 @@
 // Results differ from the LU's in rounding only (both are backward stable on these matrices); parity is asserted
 // through the tolerance of the tests, like every result beyond the closed forms.
 #include "nfm_rowwave_core.hpp"
+#include "nfm_sym_ops.hpp"
 #include "nfm_spd.hpp"
 
 #ifndef NFM_SPD_PART
@@ -495,6 +496,57 @@ static int launch_strided(const SOp &a, const SOp &b, const SOp &o, int64_t no, 
     return launch_status();
 }
 
+// y = [inp +/-] A v on compact records at any strides and two batch levels: what a channel-first field asks of
+// `sym_matvec` / `sym_addmatvec` / `sym_submatvec` at orders 9..16 (before this kernel: two packing copies and the
+// contiguous kernel).  The arithmetic is MatvecOp's (nfm_sym_ops.hpp: products and sums rounded separately, in the
+// reference's order -- the result is bit-identical to the CPU restatement whatever the layout).
+template <typename T, int N>
+__global__ __launch_bounds__(64) void matvec_strided_kernel(SOp a, SOp b, SOp c, SOp o, int64_t n, int mode)
+{
+    constexpr int K = sym_k(N);
+    using Op = MatvecOp<T, N, NFM_MAT_SYM>;
+    const T *A = static_cast<const T *>(a.ptr) + (int64_t)blockIdx.y * a.so;
+    const T *B = static_cast<const T *>(b.ptr) + (int64_t)blockIdx.y * b.so;
+    const T *C = mode != 0 ? static_cast<const T *>(c.ptr) + (int64_t)blockIdx.y * c.so : nullptr;
+    T *O = const_cast<T *>(static_cast<const T *>(o.ptr)) + (int64_t)blockIdx.y * o.so;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    T m[K], v[N], w[N], y[N];
+    {
+        const T *pa = A + i * a.si;
+#pragma unroll
+        for (int k = 0; k < K; ++k) m[k] = pa[k * a.sc];
+        const T *pb = B + i * b.si;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = pb[k * b.sc];
+#pragma unroll
+        for (int k = 0; k < N; ++k) w[k] = T(0);
+        if (mode != 0) {
+            const T *pc = C + i * c.si;
+#pragma unroll
+            for (int k = 0; k < N; ++k) w[k] = pc[k * c.sc];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0); // every load issued before the first use
+    typename Op::Params prm{mode};
+    Op::apply(m, v, w, y, prm);
+    T *po = O + i * o.si;
+#pragma unroll
+    for (int k = 0; k < N; ++k) po[k * o.sc] = y[k];
+}
+
+template <typename T, int N>
+static int launch_matvec_strided(const SOp &a, const SOp &b, const SOp &c, const SOp &o, int64_t no, int64_t n, int mode,
+                                 void *stream)
+{
+    if (n == 0 || no == 0) return NFM_OK;
+    const int64_t nblk = (n + 63) / 64;
+    if (nblk > 0x7fffffffLL || no > 65535) return NFM_EFALLBACK_RW;
+    hipLaunchKernelGGL((matvec_strided_kernel<T, N>), dim3((unsigned)nblk, (unsigned)no), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), a, b, c, o, n, mode);
+    return launch_status();
+}
+
 template <typename T, int N>
 static int call_strided(int op, const SOp &a, const SOp &b, const SOp &o, int64_t no, int64_t n, const RowParams<T> &p,
                         void *stream)
@@ -647,6 +699,11 @@ static int launch_redo(const void *a, const void *b, void *o, int64_t n, const R
     return launch_status();
 }
 
+// below this batch the second launch is not worth its 5-20 us: the wavefronts redo their bad groups themselves (a
+// batch of 6e5 general 16x16 matrices with 2 % of its groups marked: 0.46 of the roofline with the second launch,
+// 0.55 without)
+constexpr int64_t kRedoMinBatch = 1 << 20;
+
 // does the output overlap an input?  (byte ranges of contiguous operands)
 static bool ranges_overlap(const void *x, size_t xb, const void *y, size_t yb)
 {
@@ -665,7 +722,7 @@ static int launch_gen(const void *a, void *o, int64_t n, void *stream)
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
     RowParams<T> p{};
     constexpr int64_t ROUT = OP == SP_GDET ? 1 : N * N;
-    const int mark = !ranges_overlap(o, (size_t)n * ROUT * sizeof(T), a, (size_t)n * N * N * sizeof(T));
+    const int mark = n >= kRedoMinBatch && !ranges_overlap(o, (size_t)n * ROUT * sizeof(T), a, (size_t)n * N * N * sizeof(T));
     hipLaunchKernelGGL((gen_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(64), lds, static_cast<hipStream_t>(stream),
                        static_cast<const T *>(a), static_cast<T *>(o), n, p, mark);
     const int rc = launch_status();
@@ -690,7 +747,7 @@ static int launch(const void *a, const void *b, void *o, int64_t n, const RowPar
     if (nblk > 0x7fffffffLL) return NFM_ESIZE;
     constexpr int64_t K = sym_k(N), ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? K : OP == SP_INVDIAG ? N : 1;
     const size_t ob = (size_t)n * ROUT * sizeof(T);
-    const int mark = !ranges_overlap(o, ob, a, (size_t)n * K * sizeof(T)) &&
+    const int mark = n >= kRedoMinBatch && !ranges_overlap(o, ob, a, (size_t)n * K * sizeof(T)) &&
                      !(OP == SP_SOLVE && ranges_overlap(o, ob, b, (size_t)n * N * sizeof(T)));
     hipLaunchKernelGGL((spd_kernel<T, N, OP>), dim3((unsigned)nblk), dim3(64), lds, static_cast<hipStream_t>(stream),
                        static_cast<const T *>(a), static_cast<const T *>(b), static_cast<T *>(o), n, p, mark);
@@ -773,6 +830,25 @@ int NFM_SPD_SNAME1(NFM_SPD_Q)(int op, int M, int64_t no, int64_t n, const nfm_op
     return NFM_EFALLBACK_RW;
 }
 
+#if NFM_SPD_F64
+#define NFM_SPD_MNAME2(q) spd_matvec_strided_f64_q##q
+#else
+#define NFM_SPD_MNAME2(q) spd_matvec_strided_f32_q##q
+#endif
+#define NFM_SPD_MNAME1(q) NFM_SPD_MNAME2(q)
+int NFM_SPD_MNAME1(NFM_SPD_Q)(int M, int mode, int64_t no, int64_t n, const nfm_operand *a, const nfm_operand *b,
+                              const nfm_operand *c, const nfm_operand *o, void *stream)
+{
+    auto sop = [](const nfm_operand *x) {
+        return x ? spd::SOp{x->ptr, x->stride_outer, x->stride_inner, x->stride_col} : spd::SOp{nullptr, 0, 0, 0};
+    };
+    if (M == 9 + 2 * NFM_SPD_Q)
+        return spd::launch_matvec_strided<TS, 9 + 2 * NFM_SPD_Q>(sop(a), sop(b), sop(c), sop(o), no, n, mode, stream);
+    if (M == 10 + 2 * NFM_SPD_Q)
+        return spd::launch_matvec_strided<TS, 10 + 2 * NFM_SPD_Q>(sop(a), sop(b), sop(c), sop(o), no, n, mode, stream);
+    return NFM_EFALLBACK_RW;
+}
+
 #if NFM_SPD_Q == 0
 // the front end lives in the q0 object of each dtype
 static bool spd_contig(const nfm_operand *o, int64_t rec, size_t elem)
@@ -840,6 +916,29 @@ static int spd_dispatch_strided(int op, int M, int64_t no, int64_t n, const nfm_
     case 1: return NFM_SPD_SCALL(1)(op, M, no, n, a, b, o, eps, stream);
     case 2: return NFM_SPD_SCALL(2)(op, M, no, n, a, b, o, eps, stream);
     case 3: return NFM_SPD_SCALL(3)(op, M, no, n, a, b, o, eps, stream);
+    default: return NFM_EFALLBACK_RW;
+    }
+}
+
+#if NFM_SPD_F64
+#define NFM_SPD_MCALL(q) spd_matvec_strided_f64_q##q
+#else
+#define NFM_SPD_MCALL(q) spd_matvec_strided_f32_q##q
+#endif
+template <>
+int Spd<TS>::sym_matvec_strided(int M, int mode, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
+                                const nfm_operand *inp, const nfm_operand *out, void *stream)
+{
+    static const int off = [] { const char *e = roww::dbg_env("NFM_SPD_OFF"); return e ? atoi(e) : 0; }();
+    if (off == 1 || off == 3) return NFM_EFALLBACK_RW;
+    if (M < 9 || M > 16 || mat == nullptr || mat->ptr == nullptr || vec == nullptr || vec->ptr == nullptr ||
+        out == nullptr || out->ptr == nullptr || (mode != 0 && (inp == nullptr || inp->ptr == nullptr)))
+        return NFM_EFALLBACK_RW;
+    switch ((M - 9) >> 1) {
+    case 0: return NFM_SPD_MCALL(0)(M, mode, no, ni, mat, vec, inp, out, stream);
+    case 1: return NFM_SPD_MCALL(1)(M, mode, no, ni, mat, vec, inp, out, stream);
+    case 2: return NFM_SPD_MCALL(2)(M, mode, no, ni, mat, vec, inp, out, stream);
+    case 3: return NFM_SPD_MCALL(3)(M, mode, no, ni, mat, vec, inp, out, stream);
     default: return NFM_EFALLBACK_RW;
     }
 }

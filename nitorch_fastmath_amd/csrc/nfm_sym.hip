@@ -435,6 +435,10 @@ static int sym_matvec_t(int M, int kind, int mode, int64_t no, int64_t ni, const
             const int rc = Large<T>::sym_matvec(M, mode, ni, mat, vec, inp, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }
+        if (kind == NFM_MAT_SYM) { // any strides, two batch levels: every lane addresses its own record (nfm_spd.hip)
+            const int rc = Spd<T>::sym_matvec_strided(M, mode, no, ni, mat, vec, inp, out, stream);
+            if (rc != NFM_EFALLBACK) return rc;
+        }
         return big_sym_matvec<T>(M, kind, mode, no, ni, mat, vec, inp, out, stream);
     }
     MatvecParams p{mode};

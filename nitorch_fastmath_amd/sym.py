@@ -116,7 +116,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
     batch = broadcast_shapes(*shapes)
     if inp is not None and inp.shape[-1] != N:
         raise ValueError('inp and vec must have the same number of components')
-    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if N <= 8 else None)
+    out, _ = _alloc_out(out, tuple(batch) + (N,), dtype, dev, like=vec if (N <= 8 or kind == _lib.MAT_SYM) else None)
     ops = [expand_batch(batch, matv, mat_nc), expand_batch(batch, vec, 1)]
     ncs = [mat_nc, 1]
     if inp is not None:
@@ -124,7 +124,7 @@ def _matvec_impl(mode, inp, mat, vec, dtype, out):
         ncs.append(1)
     ops.append(out)
     ncs.append(1)
-    b = Batch(batch, ops, ncs, pack='all' if (N > 8 and kind == _lib.MAT_SYM) else False)
+    b = Batch(batch, ops, ncs, pack=N > 8 and kind == _lib.MAT_SYM)
     o = b.operands
     o_inp = ctypes.byref(o[2]) if inp is not None else None
     with on_device(dev):

@@ -362,6 +362,13 @@ def test_sym_large_orders_any_strides(dev, oracle, dn, M):
         assert relerr(S.sym_invert(mat_cf, diag=True).cpu().numpy().reshape(n, M), refd) <= tol
         d = S.sym_det(mat_cf).cpu().numpy().astype(np.float64).reshape(n)
         assert np.abs(d / refdet - 1).max() <= 16 * TOL[dn]
+        # sym_matvec / sym_addmatvec / sym_submatvec on the same storage: bit-identical to the oracle in any layout
+        refmv = oracle.sym_matvec(mat, vec)
+        mv = S.sym_matvec(mat_cf, vec_cf)
+        assert mv.stride() == vec_cf.stride() and np.array_equal(mv.cpu().numpy().reshape(n, M), refmv)
+        assert np.array_equal(S.sym_matvec(mat_cf, vec4).cpu().numpy().reshape(n, M), refmv)
+        assert np.array_equal(S.sym_addmatvec(vec_cf, mat_cf, vec_cf).cpu().numpy().reshape(n, M), vec + refmv)
+        assert np.array_equal(S.sym_submatvec(vec4, mat_cf, vec_cf).cpu().numpy().reshape(n, M), vec - refmv)
         # channel-first output buffers through out=
         out_cf = torch.empty(B, M, X, Y, dtype=vec4.dtype, device=dev).movedim(1, -1)
         r = S.sym_solve(mat_cf, vec_cf, out=out_cf)
@@ -415,3 +422,45 @@ def test_pivoting_always_skips_the_positive_definite_attempt(dev, oracle, dn, M)
                               oracle.sym_invert(mat, diag=True)) <= 4 * TOL[dn]
     with pytest.raises(ValueError):
         S.sym_solve(t(mat, dev), t(vec, dev), pivoting='never')
+
+
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+@pytest.mark.parametrize('M', [9, 16])
+def test_large_batches_redo_marked_groups_in_a_second_launch(dev, oracle, dn, M):
+    """batches of >= 2^20 matrices whose output aliases no input: the groups of 16 that hold a matrix which fails the
+    no-exchange test are MARKED by the first launch and redone by `redo_kernel` (nfm_spd.hip); smaller batches and
+    in-place calls redo them inside the first kernel (every other test of this file).  An indefinite (general: a
+    row-reversed) matrix every 4099, checked on the marked groups, their neighbours and both ends of the batch."""
+    dtype = np.float32 if dn == 'f32' else np.float64
+    S, B = N().sym, N().batched
+    n = (1 << 20) + 77
+    every = 4099
+    bad = np.arange(5, n, every)
+    sel = np.unique(np.concatenate([np.arange(0, 600), np.arange(n - 300, n)] +
+                                   [np.arange(max(b // 16 * 16 - 16, 0), min(b // 16 * 16 + 32, n)) for b in bad[:40]]))
+    # compact symmetric
+    mat, vec = spd_np(n, M, dtype, 4000 + M)
+    mi, _, _ = sym_indefinite_np(len(bad), M, dtype, 4100 + M, 1)
+    mat[bad] = mi
+    ms, vs = mat[sel], vec[sel]
+    assert relerr(S.sym_solve(t(mat, dev), t(vec, dev)).cpu().numpy()[sel], oracle.sym_solve(ms, vs)) <= 4 * TOL[dn]
+    if not (dn == 'f64' and M >= 14):
+        assert relerr(S.sym_invert(t(mat, dev)).cpu().numpy()[sel], oracle.sym_invert(ms)) <= 4 * TOL[dn]
+    assert relerr(S.sym_invert(t(mat, dev), diag=True).cpu().numpy()[sel], oracle.sym_invert(ms, diag=True)) <= 4 * TOL[dn]
+    d = S.sym_det(t(mat, dev)).cpu().numpy().astype(np.float64)[sel]
+    assert np.abs(d / oracle.sym_det(ms).astype(np.float64) - 1).max() <= 16 * TOL[dn]
+    # in place at the same size: the in-kernel path
+    v2 = t(vec, dev)
+    S.sym_solve_(t(mat, dev), v2)
+    assert relerr(v2.cpu().numpy()[sel], oracle.sym_solve(ms, vs)) <= 4 * TOL[dn]
+    del mat, vec, v2
+    if dn == 'f64' and M > 11:
+        return
+    # general
+    rng = np.random.default_rng(4200 + M)
+    a = (rng.standard_normal((n, M, M)) + 8 * np.eye(M)).astype(dtype)
+    a[bad] = a[bad][:, ::-1]
+    asel = a[sel]
+    assert relerr(B.batchinv(t(a, dev)).cpu().numpy()[sel], oracle.batch_inv(asel)) <= 4 * TOL[dn]
+    d = B.batchdet(t(a, dev)).cpu().numpy().astype(np.float64)[sel]
+    assert np.abs(d / oracle.batch_det(asel).astype(np.float64) - 1).max() <= 16 * TOL[dn]
