@@ -535,6 +535,74 @@ __global__ __launch_bounds__(64) void matvec_strided_kernel(SOp a, SOp b, SOp c,
     for (int k = 0; k < N; ++k) po[k * o.sc] = y[k];
 }
 
+// the same on contiguous operands with the records through LDS images (whole-line accesses): float64 orders 15, 16,
+// whose lane-by-lane kernel (nfm_large.hip, 1088-byte records) ran at 0.49 of the roofline at 16x16 (0.68 here)
+template <typename T, int N>
+constexpr int matvec_subs()
+{
+    return TileIO<T, sym_k(N), 64>::kLdsBytes <= 40 * 1024 ? 1 : 2;
+}
+template <typename T, int N, bool INP> // INP: mode != 0 (a third operand: 2 x 32 more registers at 16x16 float64)
+__global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __launch_bounds__(64) void matvec_tiled_kernel(
+    const T *__restrict__ A, const T *__restrict__ B, const T *__restrict__ C, T *__restrict__ O, int64_t n, int mode)
+{
+    constexpr int K = sym_k(N), S = matvec_subs<T, N>();
+    using Op = MatvecOp<T, N, NFM_MAT_SYM>;
+    using IM = SubIn<T, K, S>;
+    using IV = SubIn<T, N, 1>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t tile0 = (int64_t)blockIdx.x * 64;
+    const int tid = (int)threadIdx.x;
+    T m[K], v[N], w[INP ? N : 1], y[N];
+    if (n - tile0 >= 64) { // uniform: every wavefront but the last
+        typename IM::Stage sm;
+        typename IV::Stage sv, sw;
+        IM::issue(sm, A + tile0 * K, tid);
+        IV::issue(sv, B + tile0 * N, tid);
+        if constexpr (INP) IV::issue(sw, C + tile0 * N, tid);
+        IM::land(smem, sm, m, tid);
+        IV::land(smem, sv, v, tid);
+        if constexpr (INP) IV::land(smem, sw, w, tid);
+    } else {
+        IM::get_ragged(smem, m, A + tile0 * K, (n - tile0) * K, tid);
+        IV::get_ragged(smem, v, B + tile0 * N, (n - tile0) * N, tid);
+        if constexpr (INP) IV::get_ragged(smem, w, C + tile0 * N, (n - tile0) * N, tid);
+    }
+    typename Op::Params prm{INP ? mode : 0};
+    if constexpr (INP) {
+        Op::apply(m, v, w, y, prm);
+    } else {
+        T none[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) none[k] = T(0);
+        Op::apply(m, v, none, y, prm);
+    }
+    SubOut<T, N, 1>::template put<4>(smem, y, O + tile0 * N, (n - tile0) * N, tid, 0u);
+}
+
+template <typename T, int N>
+static int launch_matvec_tiled(const void *a, const void *b, const void *c, void *o, int64_t n, int mode, void *stream)
+{
+    constexpr size_t lds = SubIn<T, sym_k(N), matvec_subs<T, N>()>::kLdsBytes;
+    static_assert(lds <= 64 * 1024 && lds >= SubIn<T, N, 1>::kLdsBytes, "the images must fit the default dynamic LDS limit");
+    if (n == 0) return NFM_OK;
+    const int64_t nblk = (n + 63) / 64;
+    if (nblk > 0x7fffffffLL) return NFM_ESIZE;
+    if (mode != 0) {
+        // (16x16 float64 with a third operand is 8 registers past the file: that one case keeps its kernel of nfm_large.hip)
+        if constexpr (sizeof(T) == 8 && N == 16) return NFM_EFALLBACK_RW;
+        else
+            hipLaunchKernelGGL((matvec_tiled_kernel<T, N, true>), dim3((unsigned)nblk), dim3(64), lds,
+                               static_cast<hipStream_t>(stream), static_cast<const T *>(a), static_cast<const T *>(b),
+                               static_cast<const T *>(c), static_cast<T *>(o), n, mode);
+    } else {
+        hipLaunchKernelGGL((matvec_tiled_kernel<T, N, false>), dim3((unsigned)nblk), dim3(64), lds,
+                           static_cast<hipStream_t>(stream), static_cast<const T *>(a), static_cast<const T *>(b),
+                           static_cast<const T *>(c), static_cast<T *>(o), n, mode);
+    }
+    return launch_status();
+}
+
 template <typename T, int N>
 static int launch_matvec_strided(const SOp &a, const SOp &b, const SOp &c, const SOp &o, int64_t no, int64_t n, int mode,
                                  void *stream)
@@ -849,6 +917,21 @@ int NFM_SPD_MNAME1(NFM_SPD_Q)(int M, int mode, int64_t no, int64_t n, const nfm_
     return NFM_EFALLBACK_RW;
 }
 
+#if NFM_SPD_F64
+#define NFM_SPD_TNAME2(q) spd_matvec_tiled_f64_q##q
+#else
+#define NFM_SPD_TNAME2(q) spd_matvec_tiled_f32_q##q
+#endif
+#define NFM_SPD_TNAME1(q) NFM_SPD_TNAME2(q)
+int NFM_SPD_TNAME1(NFM_SPD_Q)(int M, int mode, int64_t n, const void *a, const void *b, const void *c, void *o, void *stream)
+{
+#if NFM_SPD_F64 && NFM_SPD_Q >= 3 // float64 15, 16 only: every other case keeps its kernel of nfm_large.hip (0.72-0.76)
+    if (M == 9 + 2 * NFM_SPD_Q) return spd::launch_matvec_tiled<TS, 9 + 2 * NFM_SPD_Q>(a, b, c, o, n, mode, stream);
+    if (M == 10 + 2 * NFM_SPD_Q) return spd::launch_matvec_tiled<TS, 10 + 2 * NFM_SPD_Q>(a, b, c, o, n, mode, stream);
+#endif
+    return NFM_EFALLBACK_RW;
+}
+
 #if NFM_SPD_Q == 0
 // the front end lives in the q0 object of each dtype
 static bool spd_contig(const nfm_operand *o, int64_t rec, size_t elem)
@@ -925,6 +1008,28 @@ static int spd_dispatch_strided(int op, int M, int64_t no, int64_t n, const nfm_
 #else
 #define NFM_SPD_MCALL(q) spd_matvec_strided_f32_q##q
 #endif
+#if NFM_SPD_F64
+#define NFM_SPD_TCALL(q) spd_matvec_tiled_f64_q##q
+#else
+#define NFM_SPD_TCALL(q) spd_matvec_tiled_f32_q##q
+#endif
+template <>
+int Spd<TS>::sym_matvec(int M, int mode, int64_t ni, const nfm_operand *mat, const nfm_operand *vec, const nfm_operand *inp,
+                        const nfm_operand *out, void *stream)
+{
+    static const int off = [] { const char *e = roww::dbg_env("NFM_SPD_OFF"); return e ? atoi(e) : 0; }();
+    const int K = M * (M + 1) / 2;
+    // (13 and 14 measured level with their kernels of nfm_large.hip: 0.68-0.70 here, 0.72 there)
+    if (off == 1 || sizeof(TS) != 8 || M < 15 || M > 16 || !spd_contig(mat, K, sizeof(TS)) ||
+        !spd_contig(vec, M, sizeof(TS)) || !spd_contig(out, M, sizeof(TS)) || (mode != 0 && !spd_contig(inp, M, sizeof(TS))))
+        return NFM_EFALLBACK_RW;
+    const void *c = mode != 0 ? inp->ptr : nullptr;
+    switch ((M - 9) >> 1) {
+    case 3: return NFM_SPD_TCALL(3)(M, mode, ni, mat->ptr, vec->ptr, c, out->ptr, stream);
+    default: return NFM_EFALLBACK_RW;
+    }
+}
+
 template <>
 int Spd<TS>::sym_matvec_strided(int M, int mode, int64_t no, int64_t ni, const nfm_operand *mat, const nfm_operand *vec,
                                 const nfm_operand *inp, const nfm_operand *out, void *stream)

@@ -432,6 +432,10 @@ static int sym_matvec_t(int M, int kind, int mode, int64_t no, int64_t ni, const
     }
     if (M > 8) {
         if (kind == NFM_MAT_SYM && no == 1) {
+            { // float64 15, 16: the records through LDS images (nfm_spd.hip)
+                const int rc = Spd<T>::sym_matvec(M, mode, ni, mat, vec, inp, out, stream);
+                if (rc != NFM_EFALLBACK) return rc;
+            }
             const int rc = Large<T>::sym_matvec(M, mode, ni, mat, vec, inp, out, stream);
             if (rc != NFM_EFALLBACK) return rc;
         }

@@ -13,6 +13,6 @@ for part in sys.argv[1:]:
     s=open(f'/root/repo/build/exp/spd/part{part}/nfm_spd-hip-amdgcn-amd-amdhsa-gfx950.s').read()
     for b in s.split('  - .agpr_count')[1:]:
         n=re.search(r'\.name:\s+(\S+)',b).group(1)
-        m=re.search(r'(matvec_strided|spd_strided|spd|gen|redo)_kernelI(\w)Li(\d+)E(?:Li(\d))?',n)
+        m=re.search(r'(matvec_tiled|matvec_strided|spd_strided|spd|gen|redo)_kernelI(\w)Li(\d+)E(?:Li(\d)|Lb(\d))?',n)
         print(m.group(1)[-3:], m.group(2), m.group(3), 'op',m.group(4), 'vgpr',re.search(r'\.vgpr_count:\s+(\d+)',b).group(1), 'scratch',re.search(r'private_segment_fixed_size: (\d+)',b).group(1), 'spill',re.search(r'vgpr_spill_count: (\d+)',b).group(1))
 P
