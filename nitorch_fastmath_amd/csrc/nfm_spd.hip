@@ -132,7 +132,9 @@ struct SubOut {
             __syncthreads();
             if (tid / L == s) {
                 unsigned char *p = lds + (tid % L) * G::kRowStride;
-                if constexpr (G::kWide) {
+                // (big float64 records go value by value: packing 136 doubles into aligned register quads for 16-byte
+                // LDS writes costs copies the float64 inverses of orders 14..16 have no registers for)
+                if constexpr (G::kWide && !(sizeof(T) == 8 && C >= 100)) {
 #pragma unroll
                     for (int q = 0; q < G::kSlots; ++q) {
                         V v;
@@ -276,6 +278,10 @@ constexpr size_t spd_lds_bytes()
 {
     constexpr int ROUT = OP == SP_SOLVE ? N : OP == SP_INV ? sym_k(N) : OP == SP_INVDIAG ? N : 1;
     size_t b = roww::tile_lds_bytes<T, N, roww_op(OP), false, 4 * fallback_rows<T>()>();
+    if (!spd_tiled<T, N>() && OP == SP_INV) {
+        const size_t t = TileIO<T, sym_k(N), 32>::kLdsBytes; // SubOut<T, K, 2>
+        b = b > t ? b : t;
+    }
     if (spd_tiled<T, N>()) {
         const size_t tm = TileIO<T, sym_k(N), 64>::kLdsBytes, tr = TileIO<T, ROUT, 64>::kLdsBytes;
         const size_t tv = TileIO<T, N, 64>::kLdsBytes;
@@ -349,6 +355,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, spd_max_waves<T, N>()))) __laun
         auto put = [&](auto &rec) {
             if constexpr (TILED) {
                 SubOut<T, ROUT, 1>::template put<NG>(smem, rec, O + tile0 * ROUT, (n - tile0) * ROUT, (int)threadIdx.x, bad);
+            } else if constexpr (OP == SP_INV) {
+                // (the lane-by-lane kernels' inverse leaves through two LDS images: whole-line stores, no packing)
+                SubOut<T, ROUT, 2>::template put<NG>(smem, rec, O + tile0 * ROUT, (n - tile0) * ROUT, (int)threadIdx.x, bad);
             } else {
                 if (mine) store_record<T, ROUT>(O + i * ROUT, rec);
             }
@@ -622,8 +631,7 @@ static int call_strided(int op, const SOp &a, const SOp &b, const SOp &o, int64_
     switch (op) {
     case SP_SOLVE: return launch_strided<T, N, SP_SOLVE>(a, b, o, no, n, p, stream);
     case SP_INV:
-        if constexpr (sizeof(T) == 8 && N >= 14) return NFM_EFALLBACK_RW; // (see call)
-        else return launch_strided<T, N, SP_INV>(a, b, o, no, n, p, stream);
+        return launch_strided<T, N, SP_INV>(a, b, o, no, n, p, stream);
     case SP_INVDIAG: return launch_strided<T, N, SP_INVDIAG>(a, b, o, no, n, p, stream);
     case SP_DET: return launch_strided<T, N, SP_DET>(a, b, o, no, n, p, stream);
     default: return NFM_EINVAL;
@@ -829,11 +837,7 @@ static int call(int op, int64_t n, const void *a, const void *b, void *o, const 
 {
     switch (op) {
     case SP_SOLVE: return launch<T, N, SP_SOLVE>(a, b, o, n, p, stream);
-    case SP_INV:
-        // float64 14..16: the record, a row of temporaries and the accumulators are past what the backend packs into
-        // 256 architectural registers + AGPR copies without scratch; those stay with the one-matrix-per-16-lanes kernels
-        if constexpr (sizeof(T) == 8 && N >= 14) return NFM_EFALLBACK_RW;
-        else return launch<T, N, SP_INV>(a, b, o, n, p, stream);
+    case SP_INV: return launch<T, N, SP_INV>(a, b, o, n, p, stream);
     case SP_INVDIAG: return launch<T, N, SP_INVDIAG>(a, b, o, n, p, stream);
     case SP_DET: return launch<T, N, SP_DET>(a, b, o, n, p, stream);
     case SP_GINV:

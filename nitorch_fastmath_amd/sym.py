@@ -306,9 +306,8 @@ def sym_invert(mat, diag=False, dtype=None, out=None, *, pivoting=None):
         from . import _bigorder
         return _bigorder.sym_invert(mat, M, bool(diag), out)
     batch = mat.shape[:-1]
-    # float64 inverses at 14..16 are the one case the strided kernels of orders 9..16 do not cover: contiguous output
     piv = _pivoting(pivoting)
-    uncovered = (M >= 14 and not diag and dtype == torch.float64) or piv
+    uncovered = piv          # (the pivoted kernels of orders 9..16 want contiguous records: everything is packed for them)
     out, _ = _alloc_out(out, tuple(batch) + ((M,) if diag else (mat.shape[-1],)), dtype, dev, like=None if uncovered else mat)
     b = Batch(batch, [mat, out], [1, 1], pack=('all' if uncovered else True) if (M > 8 and not diag) else False)
     o = b.operands

@@ -263,6 +263,6 @@ def test_no_scratch_anywhere():
     # (the 4-rows-per-lane float64 forms at orders 14..16 -- measurement forms, never the dispatch table's choice --
     # park up to 30 values in accumulation registers: 262..286)
     assert rw and max(k['vgpr'] for k in rw) <= 300 and not any(k['scratch'] for k in rw)
-    # the positive-definite-first kernels (nfm_spd.hip): every (dtype, order, op) but the float64 inverses 14..16
+    # the positive-definite-first kernels (nfm_spd.hip): every (dtype, order, op)
     sp = [k for k in rows if 'spd_kernel' in k['kernel']]
-    assert len(sp) == 2 * 8 * 4 - 3 and not any(k['scratch'] for k in sp)
+    assert len(sp) == 2 * 8 * 4 and not any(k['scratch'] for k in sp)

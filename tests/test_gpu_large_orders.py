@@ -444,8 +444,7 @@ def test_large_batches_redo_marked_groups_in_a_second_launch(dev, oracle, dn, M)
     mat[bad] = mi
     ms, vs = mat[sel], vec[sel]
     assert relerr(S.sym_solve(t(mat, dev), t(vec, dev)).cpu().numpy()[sel], oracle.sym_solve(ms, vs)) <= 4 * TOL[dn]
-    if not (dn == 'f64' and M >= 14):
-        assert relerr(S.sym_invert(t(mat, dev)).cpu().numpy()[sel], oracle.sym_invert(ms)) <= 4 * TOL[dn]
+    assert relerr(S.sym_invert(t(mat, dev)).cpu().numpy()[sel], oracle.sym_invert(ms)) <= 4 * TOL[dn]
     assert relerr(S.sym_invert(t(mat, dev), diag=True).cpu().numpy()[sel], oracle.sym_invert(ms, diag=True)) <= 4 * TOL[dn]
     d = S.sym_det(t(mat, dev)).cpu().numpy().astype(np.float64)[sel]
     assert np.abs(d / oracle.sym_det(ms).astype(np.float64) - 1).max() <= 16 * TOL[dn]
