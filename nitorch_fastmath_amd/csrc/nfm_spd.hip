@@ -33,8 +33,8 @@
 #error "compile with -DNFM_SPD_PART=0..7"
 #endif
 #ifndef NFM_GEN_F64_MAX_INV
-#define NFM_GEN_F64_MAX_INV 11 // largest float64 orders of the general no-exchange kernels (N^2 doubles per lane + staging)
-#define NFM_GEN_F64_MAX_DET 11
+#define NFM_GEN_F64_MAX_INV 13 // largest float64 orders of the general no-exchange kernels (N^2 doubles per lane + staging)
+#define NFM_GEN_F64_MAX_DET 13
 #endif
 
 namespace nfm {
@@ -250,9 +250,35 @@ struct SubIn {
             if (tid / L == s) pick(lds, r, tid);
         }
     }
+    // SEQ: one image in flight at a time (S round trips to memory, peak C + C / S registers) -- for the records that
+    // leave no room for C (S - 1) / S staging registers next to themselves (float64 general matrices at 13, 14)
+    template <bool SEQ = false>
     static __device__ __forceinline__ void get(char *smem, T (&r)[C], const T *__restrict__ g, int64_t avail, int tid)
     {
         if (avail >= (int64_t)64 * C) { // uniform: every wavefront but the last
+            if constexpr (SEQ) {
+                unsigned char *lds = reinterpret_cast<unsigned char *>(smem);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    V st[IT];
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const int q = tid + it * 64;
+                        if (G::kNVec % 64 == 0 || q < G::kNVec)
+                            st[it] = NFM_LDG(reinterpret_cast<const VG *>(g + (int64_t)s * L * C) + q);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const int q = tid + it * 64;
+                        if (G::kNVec % 64 == 0 || q < G::kNVec) *reinterpret_cast<V *>(lds + G::lds_off(q)) = st[it];
+                    }
+                    __syncthreads();
+                    if (tid / L == s) pick(lds, r, tid);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
             Stage st;
             issue(st, g, tid);
             __builtin_amdgcn_sched_barrier(0);
@@ -676,7 +702,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, gen_max_waves<T, N>()))) __laun
     const int64_t i = tile0 + threadIdx.x;
     const bool live = i < n;
     T f[N * N];
-    SubIn<T, N * N, gen_out_subs<T, N>()>::get(smem, f, A + tile0 * (N * N), (n - tile0) * (N * N), (int)threadIdx.x);
+    SubIn<T, N * N, gen_out_subs<T, N>()>::template get<(sizeof(T) == 8 && N >= 13)>(smem, f, A + tile0 * (N * N),
+                                                                                      (n - tile0) * (N * N), (int)threadIdx.x);
     if (!live) { // lanes past the end of the batch: the identity (they do not trigger the fallback)
 #pragma unroll
         for (int c = 0; c < N * N; ++c) f[c] = (c % (N + 1) == 0) ? T(1) : T(0);
