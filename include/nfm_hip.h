@@ -149,7 +149,7 @@ int nfm_sym_matmul_solve(int dtype, int K, int D, int hess_kind, int64_t n_outer
 /* out = a^-1 for general N x N matrices, `batchinv` `_impl/batched.py:101-130`.
  * N <= 3: adjugate / det; N > 3: in-register Gauss-Jordan with partial pivoting
  * (the reference falls back to LAPACK getrf/getri there); contiguous operands at
- * N = 9..16 (float64: 9..11), here and in nfm_batch_det: the elimination without row
+ * N = 9..16 (float64: 9..13), here and in nfm_batch_det: the elimination without row
  * exchanges first, accepted while every diagonal pivot is within 1/8 of its column's
  * maximum (threshold pivoting), the pivoted elimination for the groups of matrices that
  * hold one which needs an exchange -- same answers within rounding.  out may alias a. */
